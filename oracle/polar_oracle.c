@@ -1,0 +1,394 @@
+/*
+ * polar_oracle.c -- CPU restatement of the reference hot path (TEST INFRASTRUCTURE ONLY).
+ *
+ * This file is the checker for the HIP library: tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py are the only things allowed to load it.  The product path
+ * never links or calls it.
+ *
+ * Every function restates one piece of the reference (Tigrexes/polar-codes, files under cn/)
+ * in plain C, keeping the reference's data layout (the 2N-1 "heap" LLR array and the two
+ * partial-sum planes) and its order of floating-point operations so that results are
+ * bit-identical for fp64.  Parity is pinned: tests/test_oracle_golden.py checks these
+ * functions against vectors produced by running the reference itself (tools/gen_golden.py).
+ *
+ * Build: make -C oracle   (gcc -O2 -fno-fast-math -ffp-contract=off)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+static int ilog2(int n) { int k = 0; while ((1 << k) < n) k++; return k; }
+
+/* ------------------------------------------------------------------ encoder
+ * cn/polarCode.py:225-230 (rateProfile): u = 0; u[mask==1] = info, increasing index order. */
+ORC_API void orc_rate_profile(const uint8_t *info, const uint8_t *mask, int N, uint8_t *u)
+{
+    int k = 0;
+    for (int i = 0; i < N; i++) u[i] = mask[i] ? info[k++] : 0;
+}
+
+/* cn/polarCode.py:232-248 (mul_matrix): in-place butterfly, stage i pairs (j, j+2^i) for every j
+ * whose bit i is clear; natural order, no bit reversal. */
+ORC_API void orc_mul_matrix(uint8_t *x, int N)
+{
+    int n = ilog2(N);
+    for (int i = 0; i < n; i++) {
+        int d = 1 << i;
+        for (int j = 0; j < N; j++)
+            if (!(j & d)) x[j] ^= x[j + d];
+    }
+}
+
+/* cn/polarCode.py:250-255 (polarEncode). */
+ORC_API void orc_polar_encode(const uint8_t *info, const uint8_t *mask, int N, uint8_t *x)
+{
+    orc_rate_profile(info, mask, N, x);
+    orc_mul_matrix(x, N);
+}
+
+/* cn/polarCode.py:305-312 (extract). */
+ORC_API int orc_extract(const uint8_t *uhat, const uint8_t *mask, int N, uint8_t *info)
+{
+    int k = 0;
+    for (int i = 0; i < N; i++) if (mask[i]) info[k++] = uhat[i];
+    return k;
+}
+
+/* cn/functions.py:107-109 (fails). */
+ORC_API int64_t orc_fails(const uint8_t *a, const uint8_t *b, int K)
+{
+    int64_t e = 0;
+    for (int i = 0; i < K; i++) e += (a[i] != b[i]);
+    return e;
+}
+
+/* ------------------------------------------------------------------ per-path decoder state
+ * cn/polarCode.py:14-28 (class Path).  LLRs[0] is the decision LLR; "level lev" (1..n) outputs sit at
+ * [2^(lev-1)-1, 2^lev-2] and read their 2^lev inputs from [2^lev-1, 2^(lev+1)-2]; the channel LLRs
+ * sit at [N-1, 2N-2].  BITs is two planes of N-1 partial sums with the same indexing. */
+#define DEFINE_PATH(REAL, SUF)                                                                        \
+    typedef struct {                                                                                  \
+        REAL *llr;      /* 2N-1 */                                                                    \
+        uint8_t *bit0;  /* N-1  */                                                                    \
+        uint8_t *bit1;  /* N-1  */                                                                    \
+        uint8_t *uhat;  /* N    */                                                                    \
+        double pm;                                                                                    \
+    } path_##SUF;                                                                                     \
+                                                                                                      \
+    static void path_alloc_##SUF(path_##SUF *p, int N)                                                \
+    {                                                                                                 \
+        p->llr = (REAL *)calloc(2 * (size_t)N, sizeof(REAL));                                         \
+        p->bit0 = (uint8_t *)calloc(N, 1);                                                            \
+        p->bit1 = (uint8_t *)calloc(N, 1);                                                            \
+        p->uhat = (uint8_t *)calloc(N, 1);                                                            \
+        p->pm = 0.0;                                                                                  \
+    }                                                                                                 \
+    static void path_free_##SUF(path_##SUF *p) { free(p->llr); free(p->bit0); free(p->bit1); free(p->uhat); } \
+    static void path_copy_##SUF(path_##SUF *d, const path_##SUF *s, int N)                            \
+    {                                                                                                 \
+        memcpy(d->llr, s->llr, (2 * (size_t)N - 1) * sizeof(REAL));                                   \
+        memcpy(d->bit0, s->bit0, N - 1);                                                              \
+        memcpy(d->bit1, s->bit1, N - 1);                                                              \
+        memcpy(d->uhat, s->uhat, N);                                                                  \
+        d->pm = s->pm;                                                                                \
+    }                                                                                                 \
+                                                                                                      \
+    /* cn/polarCode.py:30-58 (Path.updateLLRs).  The reference passes bitreversed(i); the level it    \
+     * derives from the first '1' of that string is ctz(i)+1, used directly here.  One g level        \
+     * (cn/functions.py:115-119 lowerconv) then min-sum f levels down to index 0. */                  \
+    static int64_t update_llrs_##SUF(path_##SUF *p, int i, int n)                                     \
+    {                                                                                                 \
+        int64_t unit = 0;                                                                             \
+        int next;                                                                                     \
+        REAL *L = p->llr;                                                                             \
+        if (i == 0) {                                                                                 \
+            next = n;                                                                                 \
+        } else {                                                                                      \
+            int last = __builtin_ctz(i) + 1;                                                          \
+            int start = (1 << (last - 1)) - 1, end = (1 << last) - 2, half = 1 << (last - 1);         \
+            for (int k = start; k <= end; k++) {                                                      \
+                REAL upper = L[end + (k - start) + 1];                                                \
+                REAL lower = L[end + (k - start) + 1 + half];                                         \
+                L[k] = p->bit0[k] == 0 ? lower + upper : lower - upper;                               \
+                unit++;                                                                               \
+            }                                                                                         \
+            next = last - 1;                                                                          \
+        }                                                                                             \
+        for (int lev = next; lev >= 1; lev--) {                                                       \
+            int start = (1 << (lev - 1)) - 1, end = (1 << lev) - 2, half = 1 << (lev - 1);            \
+            for (int k = start; k <= end; k++) {                                                      \
+                REAL a = L[end + (k - start) + 1];                                                    \
+                REAL b = L[end + (k - start) + 1 + half];                                             \
+                REAL sa = (REAL)((a > 0) - (a < 0)), sb = (REAL)((b > 0) - (b < 0));                  \
+                REAL aa = a < 0 ? -a : a, ab = b < 0 ? -b : b;                                        \
+                L[k] = sa * sb * (aa < ab ? aa : ab);                                                 \
+                unit++;                                                                               \
+            }                                                                                         \
+        }                                                                                             \
+        return unit;                                                                                  \
+    }                                                                                                 \
+                                                                                                      \
+    /* cn/polarCode.py:61-85 (Path.updateBits): i even -> plane 0 of level 1; i odd -> climb          \
+     * cto(i) levels combining (a^b, b); the last combine lands in plane 0. */                        \
+    static void update_bits_##SUF(path_##SUF *p, int i, int N)                                        \
+    {                                                                                                 \
+        uint8_t b = p->uhat[i];                                                                       \
+        if (i == N - 1) return;                                                                       \
+        if (!(i & 1)) { p->bit0[0] = b; return; }                                                     \
+        int t = __builtin_ctz(~(unsigned)i); /* trailing ones */                                      \
+        p->bit1[0] = b;                                                                               \
+        for (int lev = 1; lev <= t; lev++) {                                                          \
+            int st = (1 << (lev - 1)) - 1, ed = (1 << lev) - 2, half = 1 << (lev - 1);                \
+            uint8_t *dst = (lev == t) ? p->bit0 : p->bit1;                                            \
+            for (int k = st; k <= ed; k++) {                                                          \
+                dst[ed + (k - st) + 1] = p->bit0[k] ^ p->bit1[k];                                     \
+                dst[ed + (k - st) + 1 + half] = p->bit1[k];                                           \
+            }                                                                                         \
+        }                                                                                             \
+    }
+
+DEFINE_PATH(double, f64)
+DEFINE_PATH(float, f32)
+
+/* ------------------------------------------------------------------ SC
+ * cn/polarCode.py:1525-1571 (scDecoder).  Decision: info bit -> (LLR < 0); an exactly zero LLR leaves
+ * the bit at 0 (the reference blocks on input() there and then continues with 0). Frozen -> 0.
+ * flips: optional sorted list of bit indices whose decision is inverted (the sequenceU hook). */
+#define DEFINE_SC(REAL, SUF)                                                                          \
+    ORC_API int orc_sc_decode_##SUF(const REAL *llr, const uint8_t *mask, int N, uint8_t *uhat,       \
+                                    REAL *decllr, const int32_t *flips, int nflips)                   \
+    {                                                                                                 \
+        int n = ilog2(N);                                                                             \
+        path_##SUF p;                                                                                 \
+        path_alloc_##SUF(&p, N);                                                                      \
+        memcpy(p.llr + (N - 1), llr, (size_t)N * sizeof(REAL));                                       \
+        for (int i = 0; i < N; i++) {                                                                 \
+            update_llrs_##SUF(&p, i, n);                                                              \
+            REAL d = p.llr[0];                                                                        \
+            if (decllr) decllr[i] = d;                                                                \
+            p.uhat[i] = (mask[i] && d < 0) ? 1 : 0;                                                   \
+            for (int f = 0; f < nflips; f++) if (flips[f] == i) p.uhat[i] ^= 1;                       \
+            update_bits_##SUF(&p, i, N);                                                              \
+        }                                                                                             \
+        memcpy(uhat, p.uhat, N);                                                                      \
+        path_free_##SUF(&p);                                                                          \
+        return 0;                                                                                     \
+    }
+
+DEFINE_SC(double, f64)
+DEFINE_SC(float, f32)
+
+/* ------------------------------------------------------------------ SCL
+ * Branch metric, cn/polarCode.py:982-988 and :2066-2067: Li = LLR/ln2; bm(u) = 1 - log2(1 + 2^(-Li*(-1)^u)).
+ * Evaluated in this order in fp64; 2^x overflows to +inf for x >= 1024, giving bm = -inf (never NaN). */
+static double branch_metric(double llr, int u)
+{
+    double Li = llr / log(2.0);
+    double e = u ? Li : -Li;
+    return 1.0 - log2(1.0 + pow(2.0, e));
+}
+
+/* The fp32 throughput mode of the HIP library evaluates the same quantity in the overflow-free form
+ * max(e,0) + log2(1 + 2^-|e|) and only reproduces the reference's -inf for e >= 1024. */
+static double branch_metric_f32(float llr, int u)
+{
+    float Li = llr / 0.69314718055994530942f;
+    float e = u ? Li : -Li;
+    if (e >= 1024.0f) return -INFINITY;
+    float m = e > 0 ? e : 0.0f;
+    float r = 1.0f - (m + log2f(1.0f + exp2f(-fabsf(e))));
+    return (double)r;
+}
+
+typedef struct { double pm; int pos; } cand_key;
+
+/* cn/polarCode.py:2032-2102 (sclDecoder) with :969-1005 (polarSCLFork).
+ * List order is kept exactly: below saturation list = originals ++ copies; at saturation the
+ * candidates are copies(u=1) ++ originals(u=0), stable-sorted by metric descending, first L kept in
+ * sorted order.  Final list is stable-sorted descending.  Outputs the whole sorted list.
+ * counts[0..2] = ANV, sortNum, unitCal as the reference accumulates them. */
+#define DEFINE_SCL(REAL, SUF, BM, PMR)                                                                    \
+    ORC_API int orc_scl_decode_##SUF(const REAL *llr, const uint8_t *mask, int N, int L,              \
+                                     uint8_t *uhat_all, double *pm_all, int64_t *counts)              \
+    {                                                                                                 \
+        int n = ilog2(N);                                                                             \
+        path_##SUF *list = (path_##SUF *)malloc(sizeof(path_##SUF) * 2 * L);                          \
+        path_##SUF *tmp = (path_##SUF *)malloc(sizeof(path_##SUF) * 2 * L);                           \
+        for (int j = 0; j < 2 * L; j++) path_alloc_##SUF(&list[j], N);                                \
+        int cur = 1;                                                                                  \
+        int64_t anv = 0, sortnum = 0, unit = 0;                                                       \
+        memcpy(list[0].llr + (N - 1), llr, (size_t)N * sizeof(REAL));                                 \
+        for (int i = 0; i < N; i++) {                                                                 \
+            for (int j = 0; j < cur; j++) { unit += update_llrs_##SUF(&list[j], i, n); anv++; }       \
+            if (mask[i]) {                                                                            \
+                /* fork every path: original takes u=0, copy takes u=1 */                             \
+                for (int j = 0; j < cur; j++) {                                                       \
+                    path_copy_##SUF(&list[cur + j], &list[j], N);                                     \
+                    list[j].uhat[i] = 0;                                                              \
+                    list[j].pm = PMR(list[j].pm + BM(list[j].llr[0], 0));                                            \
+                    list[cur + j].uhat[i] = 1;                                                        \
+                    list[cur + j].pm = PMR(list[cur + j].pm + BM(list[cur + j].llr[0], 1));                                \
+                }                                                                                     \
+                if (2 * cur <= L) {                                                                   \
+                    cur *= 2; /* originals ++ copies, already laid out that way */                    \
+                } else {                                                                              \
+                    /* candidates C = copies ++ originals; stable sort by pm descending */            \
+                    int nc = 2 * cur;                                                                 \
+                    int order[128];                                                                   \
+                    for (int c = 0; c < nc; c++) order[c] = (c < cur) ? cur + c : c - cur;            \
+                    for (int a = 1; a < nc; a++) { /* insertion sort is stable */                     \
+                        int v = order[a];                                                             \
+                        int b = a - 1;                                                                \
+                        while (b >= 0 && list[order[b]].pm < list[v].pm) { order[b + 1] = order[b]; b--; } \
+                        order[b + 1] = v;                                                             \
+                    }                                                                                 \
+                    sortnum++;                                                                        \
+                    for (int c = 0; c < nc; c++) tmp[c] = list[order[c]];                             \
+                    for (int c = 0; c < nc; c++) list[c] = tmp[c];                                    \
+                    cur = L;                                                                          \
+                }                                                                                     \
+            } else {                                                                                  \
+                for (int j = 0; j < cur; j++) {                                                       \
+                    list[j].uhat[i] = 0;                                                              \
+                    list[j].pm = PMR(list[j].pm + BM(list[j].llr[0], 0));                                            \
+                }                                                                                     \
+            }                                                                                         \
+            for (int j = 0; j < cur; j++) update_bits_##SUF(&list[j], i, N);                          \
+        }                                                                                             \
+        {                                                                                             \
+            int order[128];                                                                           \
+            for (int c = 0; c < cur; c++) order[c] = c;                                               \
+            for (int a = 1; a < cur; a++) {                                                           \
+                int v = order[a];                                                                     \
+                int b = a - 1;                                                                        \
+                while (b >= 0 && list[order[b]].pm < list[v].pm) { order[b + 1] = order[b]; b--; }    \
+                order[b + 1] = v;                                                                     \
+            }                                                                                         \
+            sortnum++;                                                                                \
+            for (int c = 0; c < cur; c++) {                                                           \
+                memcpy(uhat_all + (size_t)c * N, list[order[c]].uhat, N);                             \
+                pm_all[c] = list[order[c]].pm;                                                        \
+            }                                                                                         \
+        }                                                                                             \
+        if (counts) { counts[0] = anv; counts[1] = sortnum; counts[2] = unit; }                       \
+        for (int j = 0; j < 2 * L; j++) path_free_##SUF(&list[j]);                                    \
+        free(list);                                                                                   \
+        free(tmp);                                                                                    \
+        return cur;                                                                                   \
+    }
+
+#define PM_KEEP(x) (x)
+#define PM_F32(x) ((double)(float)(x))
+DEFINE_SCL(double, f64, branch_metric, PM_KEEP)
+DEFINE_SCL(float, f32, branch_metric_f32, PM_F32)
+
+/* ------------------------------------------------------------------ batched wrappers (cpu_baseline, tests) */
+ORC_API void orc_sc_decode_batch_f32(const float *llr, const uint8_t *mask, int N, int64_t B, uint8_t *uhat)
+{
+    for (int64_t b = 0; b < B; b++) orc_sc_decode_f32(llr + b * N, mask, N, uhat + b * N, NULL, NULL, 0);
+}
+ORC_API void orc_sc_decode_batch_f64(const double *llr, const uint8_t *mask, int N, int64_t B, uint8_t *uhat)
+{
+    for (int64_t b = 0; b < B; b++) orc_sc_decode_f64(llr + b * N, mask, N, uhat + b * N, NULL, NULL, 0);
+}
+
+/* ------------------------------------------------------------------ synthetic-input generator
+ * Philox4x32-10 (Salmon et al., SC'11), the counter-based generator the HIP library uses for Monte-Carlo
+ * inputs.  Not part of the reference (which draws from numpy's global MT19937, cn/simulator.py:138 and
+ * cn/channel.py:35); restated here so the device stream can be checked word for word.
+ *   key     = (seed_lo, seed_hi)
+ *   counter = (frame_lo, frame_hi, block, stream)   stream 0 = info bits, 1 = channel noise
+ *   info bit k of a frame = bit (k & 31) of word (k >> 5); word w = output (w & 3) of block (w >> 2)
+ *   noise block j -> outputs r0..r3 -> Box-Muller pairs (r0,r1) -> positions 4j,4j+1; (r2,r3) -> 4j+2,4j+3
+ *       u1 = (r + 0.5) * 2^-32 in (0,1], u2 = r' * 2^-32 in [0,1); z0 = R cos(2 pi u2), z1 = R sin(2 pi u2)
+ *   channel (cn/channel.py:19,35,56): s = 1-2x; y = s + sqrt(N0/2) z; llr = (4/N0) y                        */
+static inline void mulhilo(uint32_t a, uint32_t b, uint32_t *hi, uint32_t *lo)
+{
+    uint64_t p = (uint64_t)a * b;
+    *hi = (uint32_t)(p >> 32);
+    *lo = (uint32_t)p;
+}
+
+ORC_API void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        uint32_t hi0, lo0, hi1, lo1;
+        mulhilo(0xD2511F53u, c0, &hi0, &lo0);
+        mulhilo(0xCD9E8D57u, c2, &hi1, &lo1);
+        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+ORC_API void orc_gen_info(uint64_t seed, uint64_t frame, int K, uint8_t *info)
+{
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    for (int w4 = 0; w4 * 128 < K; w4++) {
+        uint32_t ctr[4] = {(uint32_t)frame, (uint32_t)(frame >> 32), (uint32_t)w4, 0u}, r[4];
+        orc_philox4x32_10(ctr, key, r);
+        for (int b = 0; b < 128 && w4 * 128 + b < K; b++) info[w4 * 128 + b] = (r[b >> 5] >> (b & 31)) & 1u;
+    }
+}
+
+ORC_API void orc_gen_noise(uint64_t seed, uint64_t frame, int N, double *z)
+{
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int j = 0; j * 4 < N; j++) {
+        uint32_t ctr[4] = {(uint32_t)frame, (uint32_t)(frame >> 32), (uint32_t)j, 1u}, r[4];
+        orc_philox4x32_10(ctr, key, r);
+        for (int h = 0; h < 2; h++) {
+            double u1 = ((double)r[2 * h] + 0.5) * (1.0 / 4294967296.0);
+            double u2 = (double)r[2 * h + 1] * (1.0 / 4294967296.0);
+            double R = sqrt(-2.0 * log(u1));
+            if (4 * j + 2 * h < N) z[4 * j + 2 * h] = R * cos(two_pi * u2);
+            if (4 * j + 2 * h + 1 < N) z[4 * j + 2 * h + 1] = R * sin(two_pi * u2);
+        }
+    }
+}
+
+/* One synthetic frame: info -> u -> x -> BPSK -> AWGN -> LLR (fp64). */
+ORC_API void orc_gen_frame(uint64_t seed, uint64_t frame, const uint8_t *mask, int N, int K, double N0,
+                           uint8_t *info, uint8_t *x, double *llr)
+{
+    double *z = (double *)malloc(sizeof(double) * N);
+    orc_gen_info(seed, frame, K, info);
+    orc_polar_encode(info, mask, N, x);
+    orc_gen_noise(seed, frame, N, z);
+    double sigma = sqrt(N0 / 2.0), gain = 4.0 / N0;
+    for (int i = 0; i < N; i++) llr[i] = gain * ((double)(1 - 2 * (int)x[i]) + sigma * z[i]);
+    free(z);
+}
+
+/* Monte-Carlo reference loop over [frame0, frame0+nframes): counters = frames, frame errors, bit errors.
+ * decoder: 0 = SC, 1 = SCL(L); dtype: 0 = f32 LLRs, 1 = f64 LLRs. */
+ORC_API void orc_mc_run(const uint8_t *mask, int N, int K, int decoder, int L, int dtype, double N0,
+                        uint64_t seed, uint64_t frame0, int64_t nframes, uint64_t counters[3])
+{
+    uint8_t *info = malloc(K), *x = malloc(N), *uh = malloc((size_t)N * (L > 0 ? L : 1)), *dec = malloc(K);
+    double *llr = malloc(sizeof(double) * N), *pm = malloc(sizeof(double) * (L > 0 ? L : 1));
+    float *llrf = malloc(sizeof(float) * N);
+    for (int64_t f = 0; f < nframes; f++) {
+        orc_gen_frame(seed, frame0 + f, mask, N, K, N0, info, x, llr);
+        if (dtype == 0) for (int i = 0; i < N; i++) llrf[i] = (float)llr[i];
+        if (decoder == 0) {
+            if (dtype == 0) orc_sc_decode_f32(llrf, mask, N, uh, NULL, NULL, 0);
+            else orc_sc_decode_f64(llr, mask, N, uh, NULL, NULL, 0);
+        } else {
+            if (dtype == 0) orc_scl_decode_f32(llrf, mask, N, L, uh, pm, NULL);
+            else orc_scl_decode_f64(llr, mask, N, L, uh, pm, NULL);
+        }
+        orc_extract(uh, mask, N, dec);
+        int64_t e = orc_fails(info, dec, K);
+        counters[0] += 1;
+        counters[1] += (e > 0);
+        counters[2] += (uint64_t)e;
+    }
+    free(info); free(x); free(uh); free(dec); free(llr); free(pm); free(llrf);
+}
