@@ -1,0 +1,147 @@
+/*
+ * polar_hip.h -- C ABI of libpolar_hip.so, the MI355X (gfx950) implementation of the
+ * polar encode -> BPSK/AWGN -> SC / SCL decode path.
+ *
+ * The reference (Tigrexes/polar-codes) has no FFI: its boundary is the Python object surface of
+ * cn/polarCode.py, cn/channel.py and the loop in cn/simulator.py.  Each entry point below names the
+ * reference method it stands in for; the Python classes of the same names call these through ctypes.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative POLAR_E* code on failure;
+ *     polar_last_error() returns a thread-local message for the last failure on this thread.
+ *   - `space` says where the caller's buffers live: POLAR_HOST (the library stages them through
+ *     device memory) or POLAR_DEVICE (HIP device pointers, e.g. torch tensor data_ptr()).
+ *   - bits: "bytes" buffers hold one 0/1 value per uint8; "packed" buffers hold 32 bits per
+ *     uint32 word, bit i of a frame in word i>>5 at position i&31, frames padded to whole words.
+ *   - dtype: POLAR_F32 or POLAR_F64 selects the LLR arithmetic type (float / double).
+ *   - calls are stream-ordered on the context's stream and synchronous at the ABI for POLAR_HOST;
+ *     for POLAR_DEVICE they return after enqueueing (use polar_ctx_sync or your own stream sync).
+ *   - a context and the codes made from it belong to one host thread and one GPU.
+ */
+#ifndef POLAR_HIP_H
+#define POLAR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#pragma GCC visibility push(default)
+
+typedef struct polar_ctx polar_ctx;
+typedef struct polar_code polar_code;
+
+enum { POLAR_HOST = 0, POLAR_DEVICE = 1 };
+enum { POLAR_F32 = 0, POLAR_F64 = 1 };
+enum { POLAR_DEC_SC = 0, POLAR_DEC_SCL = 1 };
+enum {
+    POLAR_OK = 0,
+    POLAR_EINVAL = -1,   /* bad argument */
+    POLAR_EHIP = -2,     /* HIP runtime error (message has the HIP error string) */
+    POLAR_ENOMEM = -3,   /* device or host allocation failed */
+    POLAR_EUNSUPPORTED = -4
+};
+/* flags for polar_sc_decode* */
+enum {
+    POLAR_SC_FAST = 1    /* skip all-frozen subtrees and hard-decide all-information subtrees
+                            (same decisions as plain SC; decision LLRs are then not available) */
+};
+
+const char *polar_last_error(void);
+/* Library version and the GPU architecture the kernels were built for ("gfx950"). */
+const char *polar_version(void);
+
+/* ---- context: one GPU, one stream, grow-only device workspace ------------------------------- */
+int polar_ctx_create(int device, polar_ctx **out);
+int polar_ctx_destroy(polar_ctx *ctx);
+/* Run on a caller-owned HIP stream (hipStream_t passed as void*); NULL restores the context's own. */
+int polar_ctx_set_stream(polar_ctx *ctx, void *hip_stream);
+int polar_ctx_sync(polar_ctx *ctx);
+/* Number of compute units of the context's GPU (for sizing reports). */
+int polar_ctx_num_cus(polar_ctx *ctx);
+
+/* ---- code object: replaces the per-code state of PolarCode.__init__ (cn/polarCode.py:116-157):
+ *      polarMask / A, plus the decoder schedules compiled from the mask.  mask: N bytes, 1 = info. */
+int polar_code_create(polar_ctx *ctx, int N, const uint8_t *mask, polar_code **out);
+int polar_code_destroy(polar_code *code);
+int polar_code_n(const polar_code *code);
+int polar_code_k(const polar_code *code);
+/* Number of decoder schedule operations: which = 0 plain SC (visits every leaf), 1 = fast SC. */
+int polar_code_schedule_len(const polar_code *code, int which);
+
+/* Host-only: writes the decoder schedule compiled from `mask` (one 32-bit word per operation, see
+ * polar-codes_amd/csrc/polar_internal.h for the encoding) into out[0..cap) and returns its length, or a
+ * negative error code.  Needs no GPU. */
+int polar_schedule_build(const uint8_t *mask, int N, int fast, uint32_t *out, int cap);
+
+/* ---- encoder: PolarCode.polarEncode = mul_matrix(rateProfile(info)) (cn/polarCode.py:225-255).
+ *      info [B x K] -> x [B x N], x = u F^{(x)n}, natural order, no bit reversal. */
+int polar_encode(polar_code *code, const uint8_t *info, uint8_t *x, int64_t B, int space);
+int polar_encode_packed(polar_code *code, const uint32_t *info, uint32_t *x, int64_t B, int space);
+/* PolarCode.mul_matrix alone (cn/polarCode.py:232-248): u [B x N] -> x [B x N]. */
+int polar_mul_matrix(polar_code *code, const uint8_t *u, uint8_t *x, int64_t B, int space);
+
+/* ---- channel: Channel.modulate + addNoise + calcLLR (cn/channel.py:16-22,33-35,53-60) for a batch.
+ *      s = 1-2x, y = s + sqrt(N0/2) z, llr = (4/N0) y; z ~ N(0,1) from Philox4x32-10 keyed by `seed`,
+ *      counter (frame0 + row, block, stream 1), Box-Muller.  llr is float or double per dtype. */
+int polar_channel_llr(polar_code *code, const uint8_t *x, void *llr, int dtype, double N0, uint64_t seed,
+                      uint64_t frame0, int64_t B, int space);
+
+/* ---- synthetic Monte-Carlo inputs: the body of the frame loop up to the decoder
+ *      (cn/simulator.py:138,148-154): random info bits (Philox stream 0), encode, channel.
+ *      Device buffers only.  info_packed [B x ceil(K/32)] (may be NULL), llr [B x N]. */
+int polar_gen_frames(polar_code *code, uint32_t *info_packed, void *llr, int dtype, double N0, uint64_t seed,
+                     uint64_t frame0, int64_t B);
+
+/* ---- SC decoder: PolarCode.scDecoder (cn/polarCode.py:1525-1571) with Path.updateLLRs /
+ *      updateBits (cn/polarCode.py:30-85) for a batch.  llr [B x N];
+ *      info_hat [B x K] = extract(uHat) (cn/polarCode.py:305-312); u_hat [B x N] or NULL;
+ *      dec_llr [B x N] decision LLRs (self.llrs) or NULL -- not available with POLAR_SC_FAST. */
+int polar_sc_decode(polar_code *code, const void *llr, int dtype, uint8_t *info_hat, uint8_t *u_hat,
+                    void *dec_llr, int64_t B, int flags, int space);
+int polar_sc_decode_packed(polar_code *code, const void *llr, int dtype, uint32_t *info_hat, uint32_t *u_hat,
+                           void *dec_llr, int64_t B, int flags, int space);
+
+/* ---- SCL decoder: PolarCode.sclDecoder + polarSCLFork (cn/polarCode.py:2032-2102, 969-1005), L <= 32.
+ *      info_hat [B x K] from the best path; pm_sorted [B x L] doubles, final path metrics in the
+ *      reference's final order (stable, descending) or NULL; u_hat_all [B x L x N] or NULL
+ *      (the whole sorted list, self.pathList[j].uHat).  Lists shorter than L (fewer than log2 L
+ *      information bits) are padded with -inf metrics and zero bits. */
+int polar_scl_decode(polar_code *code, const void *llr, int dtype, int L, uint8_t *info_hat, double *pm_sorted,
+                     uint8_t *u_hat_all, int64_t B, int space);
+int polar_scl_decode_packed(polar_code *code, const void *llr, int dtype, int L, uint32_t *info_hat,
+                            double *pm_sorted, uint32_t *u_hat_all, int64_t B, int space);
+
+/* ---- error counting: pcf.fails per frame (cn/functions.py:107-109) plus the fer/ber counters of the
+ *      driver loop (cn/simulator.py:216-226).  Adds to counters[0..2] = frames, frame errors, bit errors
+ *      (device uint64[3]).  Packed device buffers. */
+int polar_count_errors(polar_code *code, const uint32_t *info_packed, const uint32_t *info_hat_packed, int64_t B,
+                       uint64_t *counters_dev);
+
+/* ---- fused Monte-Carlo run: the frame loop of cn/simulator.py:136-156,216-226 for global frame indices
+ *      [frame0, frame0 + nframes).  Nothing but the three counters leaves the GPU.
+ *      counters (host uint64[3]) are ADDED to. Frame f always sees the same inputs whatever the chunking
+ *      or the number of GPUs, because the generator is keyed by the global frame index. */
+int polar_mc_run(polar_code *code, int decoder, int L, int dtype, int flags, double N0, uint64_t seed,
+                 uint64_t frame0, int64_t nframes, uint64_t counters[3]);
+
+/* ---- introspection for benchmarks: name, LDS bytes per frame and lanes per frame of the kernel the
+ *      last SC/SCL decode call on this code launched, its grid size, and (when timing is enabled with
+ *      polar_ctx_enable_timing) the duration of that launch in milliseconds from HIP events recorded
+ *      on the launch stream. */
+typedef struct {
+    char kernel[64];
+    int lanes_per_frame;
+    int lds_bytes_per_block;
+    int block_threads;
+    int grid_blocks;
+    float last_ms;
+} polar_launch_info;
+int polar_ctx_enable_timing(polar_ctx *ctx, int on);
+int polar_last_launch(polar_code *code, polar_launch_info *out);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif /* POLAR_HIP_H */

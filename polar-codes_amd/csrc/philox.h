@@ -1,0 +1,55 @@
+// Philox4x32-10 counter-based generator and Box-Muller transform (device side).
+//   key     = (seed_lo, seed_hi)
+//   counter = (frame_lo, frame_hi, block, stream)     stream 0 = info bits, 1 = channel noise
+// so every frame's inputs depend only on (seed, global frame index): results do not change with the
+// batch size, the chunking or the number of GPUs the frames are spread over.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+__device__ __forceinline__ void philox4x32_10(uint64_t frame, uint32_t block, uint32_t stream, uint64_t seed, uint32_t out[4])
+{
+    uint32_t c0 = (uint32_t)frame, c1 = (uint32_t)(frame >> 32), c2 = block, c3 = stream;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0;
+        c1 = lo1;
+        c2 = n2;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0;
+    out[1] = c1;
+    out[2] = c2;
+    out[3] = c3;
+}
+
+// Two standard normals from two 32-bit uniforms: u1 = (a + 0.5) 2^-32 in (0,1], u2 = b 2^-32 in [0,1).
+template <typename T> __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, T &z0, T &z1);
+
+template <> __device__ __forceinline__ void box_muller<float>(uint32_t a, uint32_t b, float &z0, float &z1)
+{
+    float u1 = ((float)a + 0.5f) * 2.3283064365386963e-10f;
+    float u2 = (float)b * 2.3283064365386963e-10f;
+    float R = sqrtf(-2.0f * logf(u1));
+    float s, c;
+    sincospif(2.0f * u2, &s, &c);
+    z0 = R * c;
+    z1 = R * s;
+}
+
+template <> __device__ __forceinline__ void box_muller<double>(uint32_t a, uint32_t b, double &z0, double &z1)
+{
+    double u1 = ((double)a + 0.5) * 2.3283064365386963e-10;
+    double u2 = (double)b * 2.3283064365386963e-10;
+    double R = sqrt(-2.0 * log(u1));
+    double s, c;
+    sincospi(2.0 * u2, &s, &c);
+    z0 = R * c;
+    z1 = R * s;
+}

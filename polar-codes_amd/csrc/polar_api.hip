@@ -1,0 +1,520 @@
+// C-ABI entry points of libpolar_hip.so: argument checking, host<->device staging, chunking.
+// The arithmetic lives in the kernels_*.hip files.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+
+#include "polar_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void polar_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *polar_last_error(void) { return g_err; }
+extern "C" const char *polar_version(void) { return "polar_hip 0.1 (gfx950)"; }
+
+int DevBuf::reserve(size_t bytes)
+{
+    if (bytes <= cap) return POLAR_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = std::max(bytes, (size_t)1 << 16);
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        polar_set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        return POLAR_ENOMEM;
+    }
+    cap = want;
+    return POLAR_OK;
+}
+void DevBuf::release()
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+// ---------------------------------------------------------------------------------------------- ctx
+extern "C" int polar_ctx_create(int device, polar_ctx **out)
+{
+    ARG_TRY(out != nullptr, "out is NULL");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) {
+        polar_set_error("device %d out of range (%d visible)", device, ndev);
+        return POLAR_EINVAL;
+    }
+    HIP_TRY(hipSetDevice(device));
+    polar_ctx *c = new (std::nothrow) polar_ctx();
+    if (!c) return POLAR_ENOMEM;
+    c->device = device;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    c->num_cus = prop.multiProcessorCount;
+    HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIP_TRY(hipEventCreate(&c->ev0));
+    HIP_TRY(hipEventCreate(&c->ev1));
+    *out = c;
+    return POLAR_OK;
+}
+
+extern "C" int polar_ctx_destroy(polar_ctx *c)
+{
+    if (!c) return POLAR_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf *bufs[] = {&c->in_bytes, &c->out_bytes, &c->in_words, &c->out_words, &c->llr_buf, &c->aux_buf,
+                      &c->aux2_buf, &c->pm_buf,    &c->counters, &c->mc_info,   &c->mc_hat};
+    for (DevBuf *b : bufs) b->release();
+    (void)hipEventDestroy(c->ev0);
+    (void)hipEventDestroy(c->ev1);
+    (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return POLAR_OK;
+}
+
+extern "C" int polar_ctx_set_stream(polar_ctx *c, void *s)
+{
+    ARG_TRY(c != nullptr, "ctx is NULL");
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return POLAR_OK;
+}
+extern "C" int polar_ctx_sync(polar_ctx *c)
+{
+    ARG_TRY(c != nullptr, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return POLAR_OK;
+}
+extern "C" int polar_ctx_num_cus(polar_ctx *c) { return c ? c->num_cus : 0; }
+extern "C" int polar_ctx_enable_timing(polar_ctx *c, int on)
+{
+    ARG_TRY(c != nullptr, "ctx is NULL");
+    c->timing = on;
+    return POLAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- schedule
+// Depth-first walk of the code tree.  A node at `level` covers leaves [pos, pos + 2^level).
+static void walk(const uint8_t *mask, int level, int pos, int plane, bool fast, std::vector<uint32_t> &ops)
+{
+    int w = 1 << level;
+    int ninfo = 0;
+    for (int i = 0; i < w; i++) ninfo += mask[pos + i] ? 1 : 0;
+    if (fast && ninfo == 0) {
+        ops.push_back(make_op(OP_R0, level, plane));
+        return;
+    }
+    if (fast && ninfo == w && level > 0) {
+        ops.push_back(make_op(OP_R1, level, plane));
+        return;
+    }
+    if (level == 0) {
+        ops.push_back(make_op(mask[pos] ? OP_LEAF_INFO : OP_LEAF_FROZEN, 0, plane, pos));
+        return;
+    }
+    ops.push_back(make_op(OP_F, level, 0));
+    walk(mask, level - 1, pos, 0, fast, ops);
+    ops.push_back(make_op(OP_G, level, 0));
+    walk(mask, level - 1, pos + w / 2, 1, fast, ops);
+    ops.push_back(make_op(OP_COMBINE, level, plane));
+}
+
+std::vector<uint32_t> build_schedule(const uint8_t *mask, int N, bool fast)
+{
+    std::vector<uint32_t> ops;
+    int n = 0;
+    while ((1 << n) < N) n++;
+    walk(mask, n, 0, 0, fast, ops);
+    ops.push_back(make_op(OP_END, 0, 0));
+    return ops;
+}
+
+extern "C" int polar_schedule_build(const uint8_t *mask, int N, int fast, uint32_t *out, int cap)
+{
+    ARG_TRY(mask != nullptr, "mask is NULL");
+    ARG_TRY(N >= 2 && N <= 65536 && (N & (N - 1)) == 0, "N must be a power of two in [2, 65536]");
+    std::vector<uint8_t> m(mask, mask + N);
+    for (auto &v : m) v = v ? 1 : 0;
+    std::vector<uint32_t> ops = build_schedule(m.data(), N, fast != 0);
+    if (out)
+        for (size_t i = 0; i < ops.size() && (int)i < cap; i++) out[i] = ops[i];
+    return (int)ops.size();
+}
+
+// ---------------------------------------------------------------------------------------------- code
+extern "C" int polar_code_create(polar_ctx *ctx, int N, const uint8_t *mask, polar_code **out)
+{
+    ARG_TRY(ctx && mask && out, "NULL argument");
+    ARG_TRY(N >= 2 && N <= 65536 && (N & (N - 1)) == 0, "N must be a power of two in [2, 65536]");
+    HIP_TRY(hipSetDevice(ctx->device));
+    polar_code *c = new (std::nothrow) polar_code();
+    if (!c) return POLAR_ENOMEM;
+    c->ctx = ctx;
+    c->N = N;
+    while ((1 << c->n) < N) c->n++;
+    c->mask.assign(mask, mask + N);
+    for (auto &m : c->mask) m = m ? 1 : 0;
+    c->Nw = (N + 31) / 32;
+    std::vector<uint32_t> maskw(c->Nw, 0), rank(c->Nw, 0), A;
+    for (int i = 0; i < N; i++) {
+        if ((i & 31) == 0) rank[i >> 5] = (uint32_t)A.size();
+        if (c->mask[i]) {
+            maskw[i >> 5] |= 1u << (i & 31);
+            A.push_back((uint32_t)i);
+        }
+    }
+    c->K = (int)A.size();
+    c->Kw = std::max(1, (c->K + 31) / 32);
+    c->sched[0] = build_schedule(c->mask.data(), N, false);
+    c->sched[1] = build_schedule(c->mask.data(), N, true);
+    if (A.empty()) A.push_back(0);
+    auto up = [&](uint32_t **dst, const std::vector<uint32_t> &v) -> int {
+        HIP_TRY(hipMalloc((void **)dst, v.size() * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(*dst, v.data(), v.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        return POLAR_OK;
+    };
+    int rc;
+    if ((rc = up(&c->d_maskw, maskw)) || (rc = up(&c->d_rank, rank)) || (rc = up(&c->d_A, A)) ||
+        (rc = up(&c->d_sched[0], c->sched[0])) || (rc = up(&c->d_sched[1], c->sched[1]))) {
+        polar_code_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return POLAR_OK;
+}
+
+extern "C" int polar_code_destroy(polar_code *c)
+{
+    if (!c) return POLAR_OK;
+    (void)hipSetDevice(c->ctx->device);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    uint32_t *ps[] = {c->d_maskw, c->d_rank, c->d_A, c->d_sched[0], c->d_sched[1]};
+    for (uint32_t *p : ps)
+        if (p) (void)hipFree(p);
+    delete c;
+    return POLAR_OK;
+}
+extern "C" int polar_code_n(const polar_code *c) { return c ? c->N : 0; }
+extern "C" int polar_code_k(const polar_code *c) { return c ? c->K : 0; }
+extern "C" int polar_code_schedule_len(const polar_code *c, int which)
+{
+    return (c && (which == 0 || which == 1)) ? (int)c->sched[which].size() : 0;
+}
+extern "C" int polar_last_launch(polar_code *c, polar_launch_info *out)
+{
+    ARG_TRY(c && out, "NULL argument");
+    *out = c->last;
+    return POLAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- helpers
+// Host-space calls are chunked so the staging buffers stay modest.
+static const int64_t HOST_CHUNK = 1 << 14;
+
+static size_t llr_size(int dtype) { return dtype == POLAR_F64 ? sizeof(double) : sizeof(float); }
+
+#define CHECK_COMMON(code, B, space)                                                      \
+    ARG_TRY((code) != nullptr, "code is NULL");                                           \
+    ARG_TRY((B) >= 0, "B must be >= 0");                                                  \
+    ARG_TRY((space) == POLAR_HOST || (space) == POLAR_DEVICE, "space must be POLAR_HOST or POLAR_DEVICE"); \
+    HIP_TRY(hipSetDevice((code)->ctx->device));                                           \
+    if ((B) == 0) return POLAR_OK
+
+// ---------------------------------------------------------------------------------------------- encode
+static int encode_bytes(polar_code *c, const uint8_t *in, uint8_t *x, int64_t B, int space, bool rate_profile)
+{
+    CHECK_COMMON(c, B, space);
+    ARG_TRY(in && x, "NULL buffer");
+    polar_ctx *ctx = c->ctx;
+    const int inbits = rate_profile ? c->K : c->N;
+    const int inw = rate_profile ? c->Kw : c->Nw;
+    int rc;
+    for (int64_t b0 = 0; b0 < B; b0 += HOST_CHUNK) {
+        int64_t nb = std::min(HOST_CHUNK, B - b0);
+        const uint8_t *din = in + b0 * inbits;
+        uint8_t *dx = x + b0 * c->N;
+        if ((rc = ctx->in_words.reserve(nb * inw * 4)) || (rc = ctx->out_words.reserve(nb * c->Nw * 4))) return rc;
+        if (space == POLAR_HOST) {
+            if ((rc = ctx->in_bytes.reserve(std::max<size_t>(1, nb * inbits))) || (rc = ctx->out_bytes.reserve(nb * c->N))) return rc;
+            if (inbits) HIP_TRY(hipMemcpyAsync(ctx->in_bytes.p, din, nb * inbits, hipMemcpyHostToDevice, ctx->stream));
+            din = ctx->in_bytes.as<uint8_t>();
+            dx = ctx->out_bytes.as<uint8_t>();
+        }
+        if ((rc = launch_pack_bits(ctx, din, ctx->in_words.as<uint32_t>(), nb, inbits))) return rc;
+        if ((rc = launch_encode(c, ctx->in_words.as<uint32_t>(), ctx->out_words.as<uint32_t>(), nb, rate_profile))) return rc;
+        if ((rc = launch_unpack_bits(ctx, ctx->out_words.as<uint32_t>(), dx, nb, c->N))) return rc;
+        if (space == POLAR_HOST) {
+            HIP_TRY(hipMemcpyAsync(x + b0 * c->N, dx, nb * c->N, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+    }
+    return POLAR_OK;
+}
+
+extern "C" int polar_encode(polar_code *c, const uint8_t *info, uint8_t *x, int64_t B, int space)
+{
+    return encode_bytes(c, info, x, B, space, true);
+}
+extern "C" int polar_mul_matrix(polar_code *c, const uint8_t *u, uint8_t *x, int64_t B, int space)
+{
+    return encode_bytes(c, u, x, B, space, false);
+}
+
+extern "C" int polar_encode_packed(polar_code *c, const uint32_t *info, uint32_t *x, int64_t B, int space)
+{
+    CHECK_COMMON(c, B, space);
+    ARG_TRY(info && x, "NULL buffer");
+    polar_ctx *ctx = c->ctx;
+    if (space == POLAR_DEVICE) return launch_encode(c, info, x, B, true);
+    int rc;
+    for (int64_t b0 = 0; b0 < B; b0 += HOST_CHUNK) {
+        int64_t nb = std::min(HOST_CHUNK, B - b0);
+        if ((rc = ctx->in_words.reserve(nb * c->Kw * 4)) || (rc = ctx->out_words.reserve(nb * c->Nw * 4))) return rc;
+        HIP_TRY(hipMemcpyAsync(ctx->in_words.p, info + b0 * c->Kw, nb * c->Kw * 4, hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = launch_encode(c, ctx->in_words.as<uint32_t>(), ctx->out_words.as<uint32_t>(), nb, true))) return rc;
+        HIP_TRY(hipMemcpyAsync(x + b0 * c->Nw, ctx->out_words.p, nb * c->Nw * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return POLAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- channel
+extern "C" int polar_channel_llr(polar_code *c, const uint8_t *x, void *llr, int dtype, double N0, uint64_t seed,
+                                 uint64_t frame0, int64_t B, int space)
+{
+    CHECK_COMMON(c, B, space);
+    ARG_TRY(x && llr, "NULL buffer");
+    ARG_TRY(dtype == POLAR_F32 || dtype == POLAR_F64, "dtype must be POLAR_F32 or POLAR_F64");
+    ARG_TRY(N0 > 0, "N0 must be positive");
+    polar_ctx *ctx = c->ctx;
+    const size_t es = llr_size(dtype);
+    int rc;
+    for (int64_t b0 = 0; b0 < B; b0 += HOST_CHUNK) {
+        int64_t nb = std::min(HOST_CHUNK, B - b0);
+        const uint8_t *dx = x + b0 * c->N;
+        char *dl = (char *)llr + b0 * c->N * es;
+        if ((rc = ctx->in_words.reserve(nb * c->Nw * 4))) return rc;
+        if (space == POLAR_HOST) {
+            if ((rc = ctx->in_bytes.reserve(nb * c->N)) || (rc = ctx->llr_buf.reserve(nb * c->N * es))) return rc;
+            HIP_TRY(hipMemcpyAsync(ctx->in_bytes.p, dx, nb * c->N, hipMemcpyHostToDevice, ctx->stream));
+            dx = ctx->in_bytes.as<uint8_t>();
+            dl = ctx->llr_buf.as<char>();
+        }
+        if ((rc = launch_pack_bits(ctx, dx, ctx->in_words.as<uint32_t>(), nb, c->N))) return rc;
+        if ((rc = launch_channel(c, ctx->in_words.as<uint32_t>(), dl, dtype, N0, seed, frame0 + b0, nb))) return rc;
+        if (space == POLAR_HOST) {
+            HIP_TRY(hipMemcpyAsync((char *)llr + b0 * c->N * es, dl, nb * c->N * es, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+    }
+    return POLAR_OK;
+}
+
+extern "C" int polar_gen_frames(polar_code *c, uint32_t *info, void *llr, int dtype, double N0, uint64_t seed,
+                                uint64_t frame0, int64_t B)
+{
+    CHECK_COMMON(c, B, POLAR_DEVICE);
+    ARG_TRY(llr != nullptr, "llr is NULL");
+    ARG_TRY(dtype == POLAR_F32 || dtype == POLAR_F64, "dtype must be POLAR_F32 or POLAR_F64");
+    ARG_TRY(N0 > 0, "N0 must be positive");
+    return launch_gen_frames(c, info, llr, dtype, N0, seed, frame0, B);
+}
+
+// ---------------------------------------------------------------------------------------------- SC
+static int sc_common(polar_code *c, const void *llr, int dtype, void *info_hat, void *u_hat, void *dec_llr,
+                     int64_t B, int flags, int space, bool packed)
+{
+    CHECK_COMMON(c, B, space);
+    ARG_TRY(llr != nullptr, "llr is NULL");
+    ARG_TRY(dtype == POLAR_F32 || dtype == POLAR_F64, "dtype must be POLAR_F32 or POLAR_F64");
+    ARG_TRY(!((flags & POLAR_SC_FAST) && dec_llr), "decision LLRs are not produced with POLAR_SC_FAST");
+    polar_ctx *ctx = c->ctx;
+    const size_t es = llr_size(dtype);
+    if (space == POLAR_DEVICE && packed)
+        return launch_sc_decode(c, llr, dtype, (uint32_t *)info_hat, (uint32_t *)u_hat, dec_llr, B, flags);
+    int rc;
+    const int64_t chunk = (space == POLAR_HOST) ? HOST_CHUNK : (int64_t)1 << 20;
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        int64_t nb = std::min(chunk, B - b0);
+        const char *dl = (const char *)llr + b0 * c->N * es;
+        char *ddec = dec_llr ? (char *)dec_llr + b0 * c->N * es : nullptr;
+        if ((rc = ctx->out_words.reserve(nb * c->Kw * 4)) || (rc = ctx->aux_buf.reserve(nb * c->Nw * 4))) return rc;
+        uint32_t *wi = ctx->out_words.as<uint32_t>(), *wu = u_hat ? ctx->aux_buf.as<uint32_t>() : nullptr;
+        if (space == POLAR_HOST) {
+            if ((rc = ctx->llr_buf.reserve(nb * c->N * es))) return rc;
+            HIP_TRY(hipMemcpyAsync(ctx->llr_buf.p, dl, nb * c->N * es, hipMemcpyHostToDevice, ctx->stream));
+            dl = ctx->llr_buf.as<char>();
+            if (dec_llr) {
+                if ((rc = ctx->aux2_buf.reserve(nb * c->N * es))) return rc;
+                ddec = ctx->aux2_buf.as<char>();
+            }
+        }
+        if ((rc = launch_sc_decode(c, dl, dtype, wi, wu, ddec, nb, flags))) return rc;
+        if (packed) {  // host + packed
+            if (info_hat) HIP_TRY(hipMemcpyAsync((uint32_t *)info_hat + b0 * c->Kw, wi, nb * c->Kw * 4, hipMemcpyDeviceToHost, ctx->stream));
+            if (u_hat) HIP_TRY(hipMemcpyAsync((uint32_t *)u_hat + b0 * c->Nw, wu, nb * c->Nw * 4, hipMemcpyDeviceToHost, ctx->stream));
+        } else {
+            uint8_t *bi = (uint8_t *)info_hat, *bu = (uint8_t *)u_hat;
+            if (space == POLAR_HOST) {
+                if ((rc = ctx->out_bytes.reserve(nb * ((size_t)c->K + c->N) + 1))) return rc;
+                uint8_t *tb = ctx->out_bytes.as<uint8_t>();
+                if (info_hat) {
+                    if ((rc = launch_unpack_bits(ctx, wi, tb, nb, c->K))) return rc;
+                    if (c->K) HIP_TRY(hipMemcpyAsync(bi + b0 * c->K, tb, nb * c->K, hipMemcpyDeviceToHost, ctx->stream));
+                }
+                if (u_hat) {
+                    uint8_t *tu = tb + nb * c->K;
+                    if ((rc = launch_unpack_bits(ctx, wu, tu, nb, c->N))) return rc;
+                    HIP_TRY(hipMemcpyAsync(bu + b0 * c->N, tu, nb * c->N, hipMemcpyDeviceToHost, ctx->stream));
+                }
+            } else {
+                if (info_hat && (rc = launch_unpack_bits(ctx, wi, bi + b0 * c->K, nb, c->K))) return rc;
+                if (u_hat && (rc = launch_unpack_bits(ctx, wu, bu + b0 * c->N, nb, c->N))) return rc;
+            }
+        }
+        if (space == POLAR_HOST) {
+            if (dec_llr) HIP_TRY(hipMemcpyAsync((char *)dec_llr + b0 * c->N * es, ddec, nb * c->N * es, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+    }
+    return POLAR_OK;
+}
+
+extern "C" int polar_sc_decode(polar_code *c, const void *llr, int dtype, uint8_t *info_hat, uint8_t *u_hat,
+                               void *dec_llr, int64_t B, int flags, int space)
+{
+    return sc_common(c, llr, dtype, info_hat, u_hat, dec_llr, B, flags, space, false);
+}
+extern "C" int polar_sc_decode_packed(polar_code *c, const void *llr, int dtype, uint32_t *info_hat, uint32_t *u_hat,
+                                      void *dec_llr, int64_t B, int flags, int space)
+{
+    return sc_common(c, llr, dtype, info_hat, u_hat, dec_llr, B, flags, space, true);
+}
+
+// ---------------------------------------------------------------------------------------------- SCL
+static int scl_common(polar_code *c, const void *llr, int dtype, int L, void *info_hat, double *pm,
+                      void *u_hat_all, int64_t B, int space, bool packed)
+{
+    CHECK_COMMON(c, B, space);
+    ARG_TRY(llr != nullptr, "llr is NULL");
+    ARG_TRY(dtype == POLAR_F32 || dtype == POLAR_F64, "dtype must be POLAR_F32 or POLAR_F64");
+    ARG_TRY(L == 1 || L == 2 || L == 4 || L == 8 || L == 16 || L == 32, "L must be a power of two in [1, 32]");
+    polar_ctx *ctx = c->ctx;
+    const size_t es = llr_size(dtype);
+    if (space == POLAR_DEVICE && packed)
+        return launch_scl_decode(c, llr, dtype, L, (uint32_t *)info_hat, pm, (uint32_t *)u_hat_all, B);
+    int rc;
+    const int64_t chunk = (space == POLAR_HOST) ? std::max<int64_t>(1, HOST_CHUNK / L) : (int64_t)1 << 18;
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        int64_t nb = std::min(chunk, B - b0);
+        const char *dl = (const char *)llr + b0 * c->N * es;
+        if ((rc = ctx->out_words.reserve(nb * c->Kw * 4)) || (rc = ctx->aux_buf.reserve(nb * L * c->Nw * 4)) ||
+            (rc = ctx->pm_buf.reserve(nb * L * sizeof(double))))
+            return rc;
+        uint32_t *wi = ctx->out_words.as<uint32_t>(), *wu = u_hat_all ? ctx->aux_buf.as<uint32_t>() : nullptr;
+        double *dpm = pm ? (space == POLAR_HOST ? ctx->pm_buf.as<double>() : pm + b0 * L) : nullptr;
+        if (space == POLAR_HOST) {
+            if ((rc = ctx->llr_buf.reserve(nb * c->N * es))) return rc;
+            HIP_TRY(hipMemcpyAsync(ctx->llr_buf.p, dl, nb * c->N * es, hipMemcpyHostToDevice, ctx->stream));
+            dl = ctx->llr_buf.as<char>();
+        }
+        if ((rc = launch_scl_decode(c, dl, dtype, L, wi, dpm, wu, nb))) return rc;
+        if (packed) {
+            if (info_hat) HIP_TRY(hipMemcpyAsync((uint32_t *)info_hat + b0 * c->Kw, wi, nb * c->Kw * 4, hipMemcpyDeviceToHost, ctx->stream));
+            if (u_hat_all) HIP_TRY(hipMemcpyAsync((uint32_t *)u_hat_all + b0 * L * c->Nw, wu, nb * L * c->Nw * 4, hipMemcpyDeviceToHost, ctx->stream));
+        } else {
+            uint8_t *bi = (uint8_t *)info_hat, *bu = (uint8_t *)u_hat_all;
+            if (space == POLAR_HOST) {
+                if ((rc = ctx->out_bytes.reserve(nb * ((size_t)c->K + (size_t)L * c->N) + 1))) return rc;
+                uint8_t *tb = ctx->out_bytes.as<uint8_t>();
+                if (info_hat) {
+                    if ((rc = launch_unpack_bits(ctx, wi, tb, nb, c->K))) return rc;
+                    if (c->K) HIP_TRY(hipMemcpyAsync(bi + b0 * c->K, tb, nb * c->K, hipMemcpyDeviceToHost, ctx->stream));
+                }
+                if (u_hat_all) {
+                    uint8_t *tu = tb + nb * c->K;
+                    if ((rc = launch_unpack_bits(ctx, wu, tu, nb * L, c->N))) return rc;
+                    HIP_TRY(hipMemcpyAsync(bu + b0 * L * c->N, tu, nb * L * c->N, hipMemcpyDeviceToHost, ctx->stream));
+                }
+            } else {
+                if (info_hat && (rc = launch_unpack_bits(ctx, wi, bi + b0 * c->K, nb, c->K))) return rc;
+                if (u_hat_all && (rc = launch_unpack_bits(ctx, wu, bu + b0 * L * c->N, nb * L, c->N))) return rc;
+            }
+        }
+        if (space == POLAR_HOST) {
+            if (pm) HIP_TRY(hipMemcpyAsync(pm + b0 * L, dpm, nb * L * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+    }
+    return POLAR_OK;
+}
+
+extern "C" int polar_scl_decode(polar_code *c, const void *llr, int dtype, int L, uint8_t *info_hat, double *pm,
+                                uint8_t *u_hat_all, int64_t B, int space)
+{
+    return scl_common(c, llr, dtype, L, info_hat, pm, u_hat_all, B, space, false);
+}
+extern "C" int polar_scl_decode_packed(polar_code *c, const void *llr, int dtype, int L, uint32_t *info_hat,
+                                       double *pm, uint32_t *u_hat_all, int64_t B, int space)
+{
+    return scl_common(c, llr, dtype, L, info_hat, pm, u_hat_all, B, space, true);
+}
+
+// ---------------------------------------------------------------------------------------------- counting / MC
+extern "C" int polar_count_errors(polar_code *c, const uint32_t *info, const uint32_t *hat, int64_t B, uint64_t *counters)
+{
+    CHECK_COMMON(c, B, POLAR_DEVICE);
+    ARG_TRY(info && hat && counters, "NULL buffer");
+    return launch_count_errors(c, info, hat, B, counters);
+}
+
+extern "C" int polar_mc_run(polar_code *c, int decoder, int L, int dtype, int flags, double N0, uint64_t seed,
+                            uint64_t frame0, int64_t nframes, uint64_t counters[3])
+{
+    ARG_TRY(c != nullptr && counters != nullptr, "NULL argument");
+    ARG_TRY(nframes >= 0, "nframes must be >= 0");
+    ARG_TRY(decoder == POLAR_DEC_SC || decoder == POLAR_DEC_SCL, "decoder must be POLAR_DEC_SC or POLAR_DEC_SCL");
+    ARG_TRY(dtype == POLAR_F32 || dtype == POLAR_F64, "dtype must be POLAR_F32 or POLAR_F64");
+    ARG_TRY(N0 > 0, "N0 must be positive");
+    if (decoder == POLAR_DEC_SCL)
+        ARG_TRY(L == 1 || L == 2 || L == 4 || L == 8 || L == 16 || L == 32, "L must be a power of two in [1, 32]");
+    polar_ctx *ctx = c->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (nframes == 0) return POLAR_OK;
+    const size_t es = llr_size(dtype);
+    // chunk so that the LLR buffer stays around 1 GiB
+    int64_t chunk = std::max<int64_t>(1024, ((int64_t)1 << 30) / ((int64_t)c->N * (int64_t)es));
+    chunk = std::min(chunk, nframes);
+    int rc;
+    if ((rc = ctx->llr_buf.reserve(chunk * c->N * es)) || (rc = ctx->mc_info.reserve(chunk * c->Kw * 4)) ||
+        (rc = ctx->mc_hat.reserve(chunk * c->Kw * 4)) || (rc = ctx->counters.reserve(3 * sizeof(uint64_t))))
+        return rc;
+    uint64_t *dcnt = ctx->counters.as<uint64_t>();
+    HIP_TRY(hipMemsetAsync(dcnt, 0, 3 * sizeof(uint64_t), ctx->stream));
+    for (int64_t f0 = 0; f0 < nframes; f0 += chunk) {
+        int64_t nb = std::min(chunk, nframes - f0);
+        if ((rc = launch_gen_frames(c, ctx->mc_info.as<uint32_t>(), ctx->llr_buf.p, dtype, N0, seed, frame0 + f0, nb))) return rc;
+        if (decoder == POLAR_DEC_SC)
+            rc = launch_sc_decode(c, ctx->llr_buf.p, dtype, ctx->mc_hat.as<uint32_t>(), nullptr, nullptr, nb, flags);
+        else
+            rc = launch_scl_decode(c, ctx->llr_buf.p, dtype, L, ctx->mc_hat.as<uint32_t>(), nullptr, nullptr, nb);
+        if (rc) return rc;
+        if ((rc = launch_count_errors(c, ctx->mc_info.as<uint32_t>(), ctx->mc_hat.as<uint32_t>(), nb, dcnt))) return rc;
+    }
+    uint64_t h[3];
+    HIP_TRY(hipMemcpyAsync(h, dcnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 3; i++) counters[i] += h[i];
+    return POLAR_OK;
+}

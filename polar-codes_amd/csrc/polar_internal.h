@@ -1,0 +1,119 @@
+// Internal declarations shared by the translation units of libpolar_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/polar_hip.h"
+
+// ---- error plumbing -------------------------------------------------------------------------
+void polar_set_error(const char *fmt, ...);
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess) {                                                                   \
+            polar_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return POLAR_EHIP;                                                                     \
+        }                                                                                          \
+    } while (0)
+#define ARG_TRY(cond, msg)                                                                         \
+    do {                                                                                           \
+        if (!(cond)) {                                                                             \
+            polar_set_error("invalid argument: %s", msg);                                          \
+            return POLAR_EINVAL;                                                                   \
+        }                                                                                          \
+    } while (0)
+
+// ---- decoder schedule -------------------------------------------------------------------------
+// One 32-bit word per operation; the list is the depth-first walk of the code tree.
+//   bits 0..3  type, bits 4..8 level (log2 of the width of the node the op belongs to),
+//   bit 9 destination plane of the node's partial sums (0 = node is a left child, 1 = right child),
+//   bits 12..31 leaf index (LEAF ops).
+enum : uint32_t {
+    OP_F = 0,        // level-(l-1) LLRs of the left child from the level-l LLRs (min-sum)
+    OP_G = 1,        // level-(l-1) LLRs of the right child, using the left child's partial sums
+    OP_LEAF_INFO = 2,
+    OP_LEAF_FROZEN = 3,
+    OP_R0 = 4,       // whole node frozen: partial sums are zero
+    OP_R1 = 5,       // whole node information: partial sums = hard decisions of its LLRs
+    OP_COMBINE = 6,  // node partial sums (xl ^ xr, xr) from its two children
+    OP_END = 15
+};
+static inline uint32_t make_op(uint32_t type, uint32_t level, uint32_t plane, uint32_t leaf = 0)
+{
+    return type | (level << 4) | (plane << 9) | (leaf << 12);
+}
+#define OP_TYPE(w) ((w)&15u)
+#define OP_LEVEL(w) (((w) >> 4) & 31u)
+#define OP_PLANE(w) (((w) >> 9) & 1u)
+#define OP_LEAFIDX(w) ((w) >> 12)
+
+std::vector<uint32_t> build_schedule(const uint8_t *mask, int N, bool fast);
+
+// ---- grow-only device buffer ------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);
+    void release();
+    template <typename T> T *as() { return reinterpret_cast<T *>(p); }
+};
+
+struct polar_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int num_cus = 0;
+    int timing = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // staging / scratch
+    DevBuf in_bytes, out_bytes, in_words, out_words, llr_buf, aux_buf, aux2_buf, pm_buf, counters, mc_info, mc_hat;
+};
+
+struct polar_code {
+    polar_ctx *ctx = nullptr;
+    int N = 0, n = 0, K = 0;
+    int Nw = 0, Kw = 0;  // words per frame (codeword / info)
+    std::vector<uint8_t> mask;
+    std::vector<uint32_t> sched[2];  // 0 = plain, 1 = fast
+    // device tables
+    uint32_t *d_maskw = nullptr;   // Nw words
+    uint32_t *d_rank = nullptr;    // Nw words: info bits before word w
+    uint32_t *d_A = nullptr;       // K info positions, ascending
+    uint32_t *d_sched[2] = {nullptr, nullptr};
+    polar_launch_info last{};
+};
+
+// ---- kernel launchers (each in its own .hip file) ----------------------------------------------
+int launch_pack_bits(polar_ctx *ctx, const uint8_t *bytes, uint32_t *words, int64_t B, int nbits);
+int launch_unpack_bits(polar_ctx *ctx, const uint32_t *words, uint8_t *bytes, int64_t B, int nbits);
+int launch_encode(polar_code *c, const uint32_t *info_or_u, uint32_t *x, int64_t B, bool rate_profile);
+int launch_channel(polar_code *c, const uint32_t *xw, void *llr, int dtype, double N0, uint64_t seed,
+                   uint64_t frame0, int64_t B);
+int launch_gen_frames(polar_code *c, uint32_t *info, void *llr, int dtype, double N0, uint64_t seed,
+                      uint64_t frame0, int64_t B);
+int launch_sc_decode(polar_code *c, const void *llr, int dtype, uint32_t *info_hat, uint32_t *u_hat,
+                     void *dec_llr, int64_t B, int flags);
+int launch_scl_decode(polar_code *c, const void *llr, int dtype, int L, uint32_t *info_hat, double *pm,
+                      uint32_t *u_hat_all, int64_t B);
+int launch_count_errors(polar_code *c, const uint32_t *info, const uint32_t *hat, int64_t B, uint64_t *counters);
+
+// timing bracket around the dominant kernel of a call
+struct LaunchTimer {
+    polar_ctx *ctx;
+    explicit LaunchTimer(polar_ctx *c) : ctx(c)
+    {
+        if (ctx->timing) (void)hipEventRecord(ctx->ev0, ctx->stream);
+    }
+    float stop()
+    {
+        if (!ctx->timing) return 0.f;
+        float ms = 0.f;
+        (void)hipEventRecord(ctx->ev1, ctx->stream);
+        (void)hipEventSynchronize(ctx->ev1);
+        (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+        return ms;
+    }
+};

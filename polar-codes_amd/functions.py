@@ -1,0 +1,159 @@
+"""Host-side function library: code construction and small helpers.
+
+Mirrors the names and results of the reference's cn/functions.py for the functions the
+encode -> channel -> SC/SCL decode path uses.  Construction is a one-off per code and stays on the
+host; masks are bit-identical to the reference's (tests/test_construction.py).
+"""
+import math
+
+import numpy as np
+
+
+def fails(list1, list2):
+    """Number of bit errors, sum |a - b| (cn/functions.py:107-109). Accepts a leading batch axis."""
+    a = np.asarray(list1).astype(np.int64)
+    b = np.asarray(list2).astype(np.int64)
+    return np.sum(np.absolute(a - b))
+
+
+def bitreversed(num: int, n) -> int:
+    """n-bit reversal of num (cn/functions.py:111-113)."""
+    r = 0
+    for _ in range(n):
+        r = (r << 1) | (num & 1)
+        num >>= 1
+    return r
+
+
+def lowerconv(upperdecision, upperllr, lowerllr):
+    """g-function of SC decoding (cn/functions.py:115-119)."""
+    return lowerllr + upperllr if upperdecision == 0 else lowerllr - upperllr
+
+
+def countOnes(num: int):
+    """Hamming weight of num (cn/functions.py:121-130)."""
+    return bin(int(num)).count("1")
+
+
+def GRowsWeight(N: int, K: int = 0):
+    """log2 of the row weights of G_N, i.e. popcount(i) (cn/functions.py:132-139)."""
+    idx = np.arange(N, dtype=np.uint64)
+    w = np.zeros(N, dtype=int)
+    for b in range(max(1, int(N).bit_length())):
+        w += ((idx >> np.uint64(b)) & np.uint64(1)).astype(int)
+    return w
+
+
+def phi_inv(x):
+    """Four-piece approximation used by the Gaussian-approximation recursion (cn/functions.py:141-149).
+    Works on scalars and arrays; every branch keeps the reference's order of operations."""
+    if np.ndim(x) == 0:
+        x = float(x)
+        if x > 12:
+            return 0.9861 * x - 2.3152
+        elif x > 3.5:
+            return x * (0.009005 * x + 0.7694) - 0.9507
+        elif x > 1:
+            return x * (0.062883 * x + 0.3678) - 0.1627
+        return x * (0.2202 * x + 0.06448)
+    x = np.asarray(x, dtype=np.float64)
+    return np.where(x > 12, 0.9861 * x - 2.3152,
+                    np.where(x > 3.5, x * (0.009005 * x + 0.7694) - 0.9507,
+                             np.where(x > 1, x * (0.062883 * x + 0.3678) - 0.1627,
+                                      x * (0.2202 * x + 0.06448))))
+
+
+def _ga_from_sigma(N, sigma_sq):
+    m = np.array([2 / sigma_sq], dtype=np.float64)
+    while m.size != N:
+        nxt = np.empty(2 * m.size, dtype=np.float64)
+        nxt[0::2] = phi_inv(m)
+        nxt[1::2] = 2 * m
+        m = nxt
+    return m
+
+
+def GA(N: int, K: int, dsnr_db: float):
+    """Mean LLRs of the N bit channels by density evolution with Gaussian approximation, natural index
+    order (cn/functions.py:201-211); design SNR is Eb/N0 in dB."""
+    sigma_sq = 1 / (2 * K / N * np.power(10, dsnr_db / 10))
+    return _ga_from_sigma(N, sigma_sq)
+
+
+def degaBuild(N: int, K: int, design_snr=0):
+    """Rate profile (1 = information, 0 = frozen) keeping the K most reliable channels; equal
+    reliabilities freeze the lower index first (cn/functions.py:484-494)."""
+    order = np.argsort(GA(N, K, design_snr), kind="stable")
+    mask = np.ones(N, dtype=int)
+    mask[order[:N - K]] = 0
+    return mask
+
+
+def rmPolarBuild(N: int, K: int, design_snr=0):
+    """Reed-Muller/polar hybrid (cn/functions.py:399-439): freeze whole row-weight classes while they
+    fit into N-K, then the least reliable members of the next class."""
+    w = GRowsWeight(N, K)
+    mu = GA(N, K, design_snr)
+    count = np.bincount(w, minlength=int(math.log2(N)) + 1)
+    mask = np.ones(N, dtype=int)
+    frozen = 0
+    k = 0
+    while frozen + count[k] <= N - K:
+        mask[w == k] = 0
+        frozen += count[k]
+        k += 1
+    cls = np.flatnonzero(w == k)
+    cls = cls[np.argsort(mu[cls], kind="stable")]
+    mask[cls[:(N - K) - frozen]] = 0
+    return mask
+
+
+def rmBuild(N: int, K: int):
+    """Pure Reed-Muller profile: the K indices of largest popcount, lower index first among equals
+    (rateProfile.m:63-68)."""
+    order = np.argsort(-GRowsWeight(N), kind="stable")
+    mask = np.zeros(N, dtype=int)
+    mask[order[:K]] = 1
+    return mask
+
+
+def rateProfile(N, K, dsnrdB, snrType, construction):
+    """MATLAB-style entry point (rateProfile.m:1-13,95-112): like the builders above but the design
+    SNR may be Es/N0 ('snr') or Eb/N0 ('snrb').  No MATLAB/Octave is available to run the original, so
+    only the 'snrb' cases are pinned (they coincide with degaBuild/rmPolarBuild away from ties)."""
+    c = construction.lower()
+    if c == "rm":
+        return rmBuild(N, K)
+    if snrType.lower() == "snr":
+        sigma_sq = 1 / (2 * np.power(10, dsnrdB / 10))
+    else:
+        sigma_sq = 1 / (2 * (K / N) * np.power(10, dsnrdB / 10))
+    mu = _ga_from_sigma(N, sigma_sq)
+    if c == "dega":
+        order = np.argsort(-mu, kind="stable")  # maxk: largest first, first occurrence wins
+        mask = np.zeros(N, dtype=int)
+        mask[order[:K]] = 1
+        return mask
+    if c == "rmpolar":
+        w = GRowsWeight(N)
+        count = np.bincount(w, minlength=int(math.log2(N)) + 1)
+        mask = np.ones(N, dtype=int)
+        frozen, k = 0, 0
+        while frozen + count[k] <= N - K:
+            mask[w == k] = 0
+            frozen += count[k]
+            k += 1
+        cls = np.flatnonzero(w == k)
+        cls = cls[np.argsort(mu[cls], kind="stable")]
+        mask[cls[:(N - K) - frozen]] = 0
+        return mask
+    raise ValueError("None such type: %r" % (construction,))
+
+
+def GN(N: int, Fn=None):
+    """Dense generator matrix F^{(x)n} (cn/functions.py:351-362).  O(N^2) memory: built only on demand."""
+    F = np.array([[1, 0], [1, 1]], dtype=int) if Fn is None else np.asarray(Fn)
+    G = np.array([[1]], dtype=int)
+    for _ in range(int(math.log2(N))):
+        G = np.kron(G, F)
+    return G

@@ -1,0 +1,184 @@
+"""PolarCode: construction on the host, encode / SC / SCL decode on the GPU.
+
+Keeps the names, argument meaning and return types of the reference's cn/polarCode.py for the
+encode -> decode path (constructor attributes, rateProfile, mul_matrix, polarEncode, extract, decode,
+scDecoder, sclDecoder).  Every method also accepts a leading batch axis [B, ...].  The arithmetic runs
+in libpolar_hip.so through ctypes; there is no CPU fallback.
+"""
+import math
+
+import numpy as np
+
+import _native
+import functions as pcfun
+
+
+class Path:
+    """Read-only view of one surviving SCL path (cn/polarCode.py:14-28 keeps full decoder state per
+    path; after decoding only uHat and pathMetric are meaningful, and those are what is exposed)."""
+
+    def __init__(self, uHat, pathMetric):
+        self.uHat = uHat
+        self.pathMetric = pathMetric
+
+
+class PolarCode:
+    def __init__(self, N, K, construct, dSNR, stackSize=0, listSize=0, gen=[]):
+        """Same signature as cn/polarCode.py:116.  `construct` in {'dega', 'rmpolar'} (case-insensitive);
+        the reference's 'ws' and 'my' constructions belong to the PAC code family and are not provided."""
+        self.codewordLength = N
+        self.infoLen = K
+        self.n = int(math.log2(N))
+        self.designSNR = dSNR
+        self.indicesRev = [pcfun.bitreversed(i, self.n) for i in range(N)]
+        c = construct.lower()
+        if c == "dega":
+            self.polarMask = pcfun.degaBuild(N, K, dSNR)
+        elif c == "rmpolar":
+            self.polarMask = pcfun.rmPolarBuild(N, K, dSNR)
+        elif c == "rm":
+            self.polarMask = pcfun.rmBuild(N, K)
+        else:
+            raise NotImplementedError("construction %r is not provided (use 'dega', 'rmpolar' or 'rm')" % (construct,))
+        self._init_common(stackSize, listSize, gen)
+
+    @classmethod
+    def from_mask(cls, mask, dSNR=0.0, listSize=0):
+        """Code object around an explicit rate profile (1 = information bit)."""
+        self = cls.__new__(cls)
+        mask = np.asarray(mask).astype(int)
+        self.codewordLength = int(mask.size)
+        self.infoLen = int(mask.sum())
+        self.n = int(math.log2(mask.size))
+        self.designSNR = dSNR
+        self.indicesRev = [pcfun.bitreversed(i, self.n) for i in range(mask.size)]
+        self.polarMask = mask
+        self._init_common(0, listSize, [])
+        return self
+
+    def _init_common(self, stackSize, listSize, gen):
+        N = self.codewordLength
+        self.frozenMask = (self.polarMask + 1) % 2
+        self.A = np.array(range(N), dtype=int)[self.polarMask == 1]
+        self.Fn = np.array([[1, 0], [1, 1]])
+        self.gen = gen
+        self.m = len(gen) - 1
+        self.snrType = ""
+        self.modu = ""
+        self.D = stackSize
+        self.L = listSize
+        self.isCRC = False
+        self.crcWidth = 0
+        self.decoderType = "sc"
+        self.dtype = np.float64  # arithmetic type of the decoders: float64 = parity with the reference
+        self._code = None
+
+    # ---- lazily built pieces ------------------------------------------------------------------------
+    @property
+    def GN(self):
+        """Dense generator matrix (cn/polarCode.py:131).  O(N^2): only built when asked for."""
+        if "_GN" not in self.__dict__:
+            self._GN = pcfun.GN(self.codewordLength, self.Fn)
+        return self._GN
+
+    @property
+    def native(self):
+        """Device-side code object; created on first use (raises if the GPU library is unavailable)."""
+        if self._code is None:
+            self._code = _native.Code(_native.default_ctx(), self.polarMask)
+        return self._code
+
+    # ---- encode -------------------------------------------------------------------------------------
+    def rateProfile(self, info):
+        """u = 0; u[polarMask == 1] = info (cn/polarCode.py:225-230)."""
+        info = np.asarray(info)
+        u = np.zeros(info.shape[:-1] + (self.codewordLength,), dtype=int)
+        u[..., self.polarMask == 1] = info
+        return u
+
+    def mul_matrix(self, u):
+        """x = u F^{(x)n} mod 2, natural order; like the reference (cn/polarCode.py:232-248) the result is
+        written back into `u` when it is an integer ndarray, and returned."""
+        arr = np.asarray(u)
+        x = self.native.mul_matrix(arr.reshape(-1, self.codewordLength)).reshape(arr.shape)
+        if isinstance(u, np.ndarray) and np.issubdtype(u.dtype, np.integer):
+            u[...] = x
+            return u
+        return x.astype(int)
+
+    def polarEncode(self, info):
+        """mul_matrix(rateProfile(info)) in one GPU call (cn/polarCode.py:250-255)."""
+        info = np.asarray(info)
+        x = self.native.encode(info.reshape(int(np.prod(info.shape[:-1], dtype=np.int64)), self.infoLen))
+        return x.reshape(info.shape[:-1] + (self.codewordLength,)).astype(int)
+
+    def extract(self, uHat):
+        """uHat[polarMask == 1] in index order (cn/polarCode.py:305-312)."""
+        return np.asarray(uHat)[..., self.polarMask == 1].astype(int)
+
+    # ---- decode -------------------------------------------------------------------------------------
+    def decode(self, softMess, y=[], LMax=0):
+        """String dispatch on self.decoderType like cn/polarCode.py:316-350; 'sc' and 'scl' are provided."""
+        t = self.decoderType.lower()
+        if t == "sc":
+            return self.scDecoder(softMess)
+        if t == "scl":
+            return self.sclDecoder(softMess)
+        raise NotImplementedError("decoder type %r is not provided (the reference blocks on input() here)" % (self.decoderType,))
+
+    def _llr(self, softMess):
+        a = np.asarray(softMess)
+        if a.dtype != np.float32 or np.dtype(self.dtype) == np.float64:
+            a = a.astype(self.dtype)
+        return a
+
+    def scDecoder(self, softMess, sequenceU=[]):
+        """Successive cancellation (cn/polarCode.py:1525-1571).  Sets self.uHat, self.llrs (decision LLRs),
+        self.ANV = N like the reference; returns the decoded information bits."""
+        if len(sequenceU):
+            raise NotImplementedError("bit flipping (sequenceU) is not provided")
+        llr = self._llr(softMess)
+        batch = llr.shape[:-1]
+        info, uh, dl = self.native.sc_decode(llr.reshape(-1, self.codewordLength), want_uhat=True, want_llrs=True)
+        self.uHat = uh.reshape(batch + (self.codewordLength,)).astype(int)
+        self.llrs = dl.reshape(batch + (self.codewordLength,))
+        self.ANV = self.codewordLength
+        self.mT = -6
+        self.predictIdx = []
+        return info.reshape(batch + (self.infoLen,)).astype(int)
+
+    def sclDecoder(self, softMess, isCRC=False, isRCPP=False):
+        """List decoding with list size self.L (cn/polarCode.py:2032-2102, 969-1005).  Sets self.pathList
+        (survivors sorted by metric, descending, ties in the reference's stable order), self.ANV,
+        self.sortNum, self.unitCal; returns the information bits of the best path."""
+        if isCRC or isRCPP:
+            raise NotImplementedError("CRC-aided selection and puncturing are not provided")
+        L = int(self.L)
+        llr = self._llr(softMess)
+        batch = llr.shape[:-1]
+        info, pm, uh = self.native.scl_decode(llr.reshape(-1, self.codewordLength), L, want_list=True)
+        nsurv = min(L, 2 ** self.infoLen) if self.infoLen < 6 else L
+        if batch == ():
+            self.pathList = [Path(uh[0, j].astype(int), pm[0, j]) for j in range(nsurv)]
+        else:
+            self.pathList = [[Path(uh[b, j].astype(int), pm[b, j]) for j in range(nsurv)] for b in range(uh.shape[0])]
+        self.pathMetrics = pm.reshape(batch + (L,))
+        self.ANV, self.sortNum, self.unitCal = self._scl_counts(L)
+        return info.reshape(batch + (self.infoLen,)).astype(int)
+
+    def _scl_counts(self, L):
+        """Complexity counters of the reference's sclDecoder in closed form: they depend only on the
+        rate profile (list size doubles per information bit until it reaches L)."""
+        cur, anv, sorts, unit = 1, 0, 0, 0
+        N, n = self.codewordLength, self.n
+        for i in range(N):
+            per_path = N - 1 if i == 0 else (1 << ((i & -i).bit_length())) - 1
+            unit += per_path * cur
+            anv += cur
+            if self.polarMask[i] == 1:
+                if 2 * cur <= L:
+                    cur *= 2
+                else:
+                    sorts += 1
+                    cur = L
+        return anv, sorts + 1, unit

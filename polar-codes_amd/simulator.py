@@ -1,0 +1,186 @@
+"""Monte-Carlo BER/FER driver: the frame loop of the reference's cn/simulator.py as a function.
+
+The reference's loop (cn/simulator.py:117-285) draws a message, encodes, adds noise, decodes and counts
+errors one frame at a time.  Here one call of the GPU library does that for a whole batch of frames
+(random info bits and Philox noise generated on the device; only three counters come back), frames are
+sharded over the ranks of a torch.distributed job (one process per GPU) and the counters are summed with
+one all-reduce (RCCL when the tensors live on the GPU).
+
+Frame f of an SNR point always sees the same message and noise, whatever the batch size or the number
+of ranks, because the generator is keyed by (seed, global frame index).
+"""
+import os
+import time
+
+import numpy as np
+
+from channel import Channel
+
+
+class BERFER:
+    """Result container with the reference's field names (cn/simulator.py:109-115) plus raw counts."""
+
+    def __init__(self):
+        self.snrRange = list()
+        self.ber = list()
+        self.fer = list()
+        self.frames = list()
+        self.frameErrors = list()
+        self.bitErrors = list()
+        self.seconds = list()
+
+    def as_dict(self):
+        return {k: list(map(float, v)) for k, v in self.__dict__.items()}
+
+
+def _dist_state(dist):
+    """(rank, world, all_reduce) for an initialised torch.distributed process group, or a single rank."""
+    if dist is None:
+        try:
+            import torch.distributed as td
+
+            if td.is_available() and td.is_initialized():
+                dist = td
+        except ImportError:
+            dist = None
+    if dist is None:
+        return 0, 1, None
+    return dist.get_rank(), dist.get_world_size(), dist
+
+
+def _all_reduce_counters(dist, counters, device):
+    """Sum uint64[3] counters over all ranks; tensors on `device` ('cuda:<i>' -> RCCL, 'cpu' -> gloo)."""
+    if dist is None:
+        return counters
+    import torch
+
+    t = torch.tensor([int(c) for c in counters], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return np.array(t.cpu().tolist(), dtype=np.uint64)
+
+
+def shard_range(total, rank, world):
+    """Contiguous share [lo, hi) of `total` frames for `rank` (sizes differ by at most one)."""
+    base, rem = divmod(int(total), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def native_runner(pcode, decoder, L, dtype):
+    """Default frame runner: polar_mc_run of the GPU library."""
+    import _native
+
+    dec = _native.DEC_SCL if decoder == "scl" else _native.DEC_SC
+
+    def run(N0, seed, frame0, nframes):
+        return pcode.native.mc_run(dec, L, dtype, N0, seed, frame0, nframes)
+
+    return run
+
+
+def simulate(pcode, snrRange, frames=None, errCnt=100, minFrames=100000, maxFrames=10 ** 8, seed=2024, decoder=None,
+             L=None, dtype=np.float32, batch=1 << 18, snrType=None, modu=None, verbose=True, dist=None, runner=None,
+             reduce_device=None):
+    """Eb/N0 (or Es/N0) sweep.
+
+    frames=int   -> exactly that many frames per SNR point (split evenly over the ranks);
+    frames=None  -> the reference's stopping rule `fer >= errCnt and t >= minFrames - 1`
+                    (cn/simulator.py:257, errCnt=100, t >= 99999), tested after every round of
+                    world_size * batch frames, so a point may overshoot by less than one round.
+    decoder/L/snrType/modu default to the attributes set on `pcode` like the reference's driver does
+    (cn/simulator.py:78-83).  Returns a BERFER; every rank returns the same totals.
+    """
+    rank, world, dist = _dist_state(dist)
+    decoder = (decoder or getattr(pcode, "decoderType", "sc") or "sc").lower()
+    if decoder not in ("sc", "scl"):
+        raise NotImplementedError("decoder %r is not provided" % (decoder,))
+    L = int(L if L is not None else (getattr(pcode, "L", 0) or 1))
+    snrType = snrType or getattr(pcode, "snrType", "") or "SNRb"
+    modu = modu or getattr(pcode, "modu", "") or "BPSK"
+    rate = pcode.infoLen / pcode.codewordLength
+    run = runner or native_runner(pcode, decoder, L, dtype)
+    if reduce_device is None:
+        reduce_device = "cpu"
+        if dist is not None and dist.get_backend() == "nccl":
+            reduce_device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
+    result = BERFER()
+    for ip, snr in enumerate(snrRange):
+        snr = float(snr)
+        if verbose and rank == 0:
+            print(f"\nSNR = {snr} dB")
+        ch = Channel(modu, snr, snrType, rate)
+        pseed = int(seed) + ip
+        total = np.zeros(3, dtype=np.uint64)
+        t0 = time.perf_counter()
+        if frames is not None:
+            lo, hi = shard_range(frames, rank, world)
+            mine = np.zeros(3, dtype=np.uint64)
+            for f0 in range(lo, hi, batch):
+                mine += run(ch.noisePower, pseed, f0, min(batch, hi - f0))
+            total = _all_reduce_counters(dist, mine, reduce_device)
+        else:
+            rnd = 0
+            while True:
+                f0 = (rnd * world + rank) * batch
+                mine = run(ch.noisePower, pseed, f0, batch)
+                total += _all_reduce_counters(dist, mine, reduce_device)
+                rnd += 1
+                t = int(total[0]) - 1
+                if verbose and rank == 0:
+                    print(f"\nt = {t} FER = {int(total[1]) / (t + 1):0.2e}")
+                if (int(total[1]) >= errCnt and t >= minFrames - 1) or int(total[0]) >= maxFrames:
+                    break
+        dt = time.perf_counter() - t0
+        nfr, fe, be = int(total[0]), int(total[1]), int(total[2])
+        if verbose and rank == 0:
+            print(f"\nAt {snr} dB FER is {fe / max(nfr, 1):0.2e}")
+        result.snrRange.append(snr)
+        result.ber.append(be / max(nfr * pcode.infoLen, 1))
+        result.fer.append(fe / max(nfr, 1))
+        result.frames.append(nfr)
+        result.frameErrors.append(fe)
+        result.bitErrors.append(be)
+        result.seconds.append(dt)
+    return result
+
+
+def main(argv=None):
+    """Small command line around simulate(): python simulator.py --N 1024 --K 512 --decoder scl --L 8 ..."""
+    import argparse
+    import json
+
+    from polarCode import PolarCode
+
+    ap = argparse.ArgumentParser(description="Polar code BER/FER sweep on MI355X")
+    ap.add_argument("--N", type=int, default=1024)
+    ap.add_argument("--K", type=int, default=512)
+    ap.add_argument("--construct", default="dega")
+    ap.add_argument("--dsnr", type=float, default=2.0)
+    ap.add_argument("--decoder", default="sc", choices=["sc", "scl"])
+    ap.add_argument("--L", type=int, default=8)
+    ap.add_argument("--snr", type=float, nargs="+", default=[1.0, 1.5, 2.0, 2.5, 3.0])
+    ap.add_argument("--frames", type=int, default=None)
+    ap.add_argument("--errCnt", type=int, default=100)
+    ap.add_argument("--minFrames", type=int, default=100000)
+    ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--f64", action="store_true")
+    a = ap.parse_args(argv)
+    dist = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl")
+    pc = PolarCode(a.N, a.K, a.construct, a.dsnr, listSize=a.L)
+    pc.decoderType, pc.snrType, pc.modu = a.decoder, "SNRb", "BPSK"
+    res = simulate(pc, a.snr, frames=a.frames, errCnt=a.errCnt, minFrames=a.minFrames, seed=a.seed,
+                   dtype=np.float64 if a.f64 else np.float32, dist=dist)
+    if dist is None or dist.get_rank() == 0:
+        print(json.dumps(res.as_dict()))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

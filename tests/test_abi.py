@@ -1,0 +1,85 @@
+"""The C-ABI library loads without a GPU and exports every symbol the header declares; the host-side
+schedule compiler is checked against the CPU oracle through a numpy interpreter of its output."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import _native
+import functions as pcf
+from frames import make_frame
+from oracle import oracle
+from sched_sim import OP_LEAF_FROZEN, OP_LEAF_INFO, OP_R0, OP_R1, decode_op, run_schedule
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "polar_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(polar_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported():
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/polar_hip.h but not exported"
+    assert sorted(_native.SIGNATURES) == names, "ctypes signature table and header disagree"
+
+
+def test_version_and_error_string():
+    L = _native.lib()
+    assert b"gfx950" in L.polar_version()
+    assert L.polar_schedule_build(None, 8, 0, None, 0) == -1
+    assert b"mask" in L.polar_last_error()
+    m = np.ones(12, dtype=np.uint8)
+    assert L.polar_schedule_build(m.ctypes.data, 12, 0, None, 0) == -1  # not a power of two
+
+
+def test_product_path_has_no_cpu_fallback():
+    """Without a GPU the product classes must raise instead of computing on the host."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from polarCode import PolarCode
+
+    pc = PolarCode(8, 4, "dega", 2.0)
+    with pytest.raises(_native.PolarError):
+        pc.polarEncode([1, 0, 1, 1])
+    for mod in ("polarCode", "channel", "functions", "simulator", "_native"):
+        text = open(os.path.join(ROOT, "polar-codes_amd", mod + ".py")).read()
+        assert "oracle" not in text, f"{mod}.py must not reference the oracle"
+
+
+@pytest.mark.parametrize("N,K,cons", [(8, 4, "dega"), (128, 64, "dega"), (1024, 512, "dega"), (512, 256, "rmpolar"), (256, 30, "dega"), (256, 230, "dega")])
+def test_schedules_decode_like_the_oracle(N, K, cons):
+    mask = pcf.degaBuild(N, K, 2.0) if cons == "dega" else pcf.rmPolarBuild(N, K, 2.0)
+    plain = _native.schedule_build(mask, False)
+    fast = _native.schedule_build(mask, True)
+    types = [decode_op(w)[0] for w in plain]
+    assert types.count(OP_LEAF_INFO) == K and types.count(OP_LEAF_FROZEN) == N - K
+    assert OP_R0 not in types and OP_R1 not in types
+    assert len(fast) < len(plain)
+    for seed in range(6):
+        msg, x, llr = make_frame(mask, 1.0 + 0.5 * seed, 300 + seed, oracle.polar_encode)
+        uh, dl = oracle.sc_decode(llr, mask, want_llrs=True)
+        u1, d1 = run_schedule(plain, llr, N)
+        assert np.array_equal(u1, uh)
+        assert d1.tobytes() == dl.tobytes()  # every leaf visited, same arithmetic
+        u2, _ = run_schedule(fast, llr, N)
+        assert np.array_equal(u2, uh)  # pruned schedule: same decisions
+
+
+def test_schedule_edge_profiles():
+    for mask in (np.zeros(16, int), np.ones(16, int), np.array([0, 1] * 8), np.array([0] * 8 + [1] * 8)):
+        plain = _native.schedule_build(mask, False)
+        fast = _native.schedule_build(mask, True)
+        llr = np.random.RandomState(5).standard_normal(16) * 3
+        uh = oracle.sc_decode(llr, mask)
+        assert np.array_equal(run_schedule(plain, llr, 16)[0], uh)
+        assert np.array_equal(run_schedule(fast, llr, 16)[0], uh)

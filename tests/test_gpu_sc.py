@@ -1,0 +1,136 @@
+"""GPU parity of the SC decoder: bit-exact uHat and decision LLRs against the reference's vectors and the
+oracle in fp64; bit-exact against the fp32 oracle in fp32; fast schedule == plain schedule."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import _native
+import functions as pcf
+from channel import Channel
+from frames import make_frame, pack, unpack
+from oracle import oracle
+from polarCode import PolarCode
+
+pytestmark = pytest.mark.gpu
+
+SC_TAGS = [("dega", 128, 64, 1.0), ("dega", 128, 64, 2.0), ("dega", 128, 64, 4.0), ("dega", 1024, 512, 1.0),
+           ("dega", 1024, 512, 2.0), ("dega", 1024, 512, 3.0), ("rmpolar", 512, 256, 2.0), ("dega", 16384, 8192, 2.0)]
+
+
+def test_sc_kat_8_4(golden):
+    g = golden.sc
+    pc = PolarCode(8, 4, "dega", 2.0)
+    pc.decoderType = "SC"
+    dec = pc.decode(g["kat8_llr"])
+    assert dec.tolist() == [1, 1, 1, 1] and dec.dtype.kind == "i"
+    assert pc.uHat.tolist() == [0, 0, 0, 1, 0, 1, 1, 1]
+    assert pc.llrs.tolist() == [1, -3, 1.5, -3.5, -2.5, -2, -6, -31.1]
+    assert pc.ANV == 8
+
+
+@pytest.mark.parametrize("cons,N,K,snr", SC_TAGS)
+def test_sc_fp64_matches_reference_vectors(golden, cons, N, K, snr):
+    g = golden.sc
+    tag = f"{cons}_{N}_{K}_{snr}"
+    pc = PolarCode(N, K, cons, 2.0)
+    seeds = g[f"{tag}_seeds"]
+    frames = [make_frame(pc.polarMask, snr, int(s), oracle.polar_encode) for s in seeds]
+    llr = np.stack([f[2] for f in frames])
+    dec = pc.scDecoder(llr)  # one batched call
+    assert np.array_equal(pack(pc.uHat), g[f"{tag}_uhat"])
+    for f in range(len(seeds)):
+        assert hashlib.sha1(pc.llrs[f].tobytes()).digest() == g[f"{tag}_decllr_sha1"][f].tobytes(), (tag, f)
+        assert int(np.sum(dec[f] != frames[f][0])) == int(g[f"{tag}_biterr"][f])
+    # fast schedule (frozen subtrees skipped, all-information subtrees hard-decided): same bits
+    info_fast, uh_fast, _ = pc.native.sc_decode(llr, want_uhat=True, fast=True)
+    assert np.array_equal(uh_fast, pc.uHat)
+    assert np.array_equal(info_fast, dec)
+
+
+@pytest.mark.parametrize("lanes", [8, 16, 32, 64])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_sc_every_lane_width_vs_oracle(monkeypatch, lanes, dtype):
+    """All lane-group widths of the kernel, ragged batch sizes, both arithmetic types."""
+    monkeypatch.setenv("POLAR_SC_LANES", str(lanes))
+    rs = np.random.RandomState(lanes)
+    for N, K in [(64, 20), (256, 128), (1024, 512)]:
+        mask = pcf.degaBuild(N, K, 2.0)
+        code = _native.Code(_native.default_ctx(), mask)
+        B = 1 + 64 // lanes * 3 + 1  # not a multiple of the frames-per-wavefront
+        frames = [make_frame(mask, 1.5, int(rs.randint(1 << 30)), oracle.polar_encode) for _ in range(B)]
+        llr = np.stack([f[2] for f in frames]).astype(dtype)
+        info, uh, dl = code.sc_decode(llr, want_uhat=True, want_llrs=True)
+        assert code.last_launch()["lanes_per_frame"] == lanes
+        for b in range(B):
+            ruh, rdl = oracle.sc_decode(llr[b], mask, want_llrs=True)
+            assert np.array_equal(uh[b], ruh), (N, b)
+            assert np.array_equal(dl[b], rdl), (N, b)
+            assert np.array_equal(info[b], oracle.extract(ruh, mask))
+        info_f, uh_f, _ = code.sc_decode(llr, want_uhat=True, fast=True)
+        assert np.array_equal(uh_f, uh)
+
+
+@pytest.mark.parametrize("N", [2, 4, 8, 16, 32, 64])
+def test_sc_small_lengths_and_extreme_rates(N):
+    rs = np.random.RandomState(N)
+    for K in sorted({0, 1, N // 2, N - 1, N}):
+        mask = np.zeros(N, dtype=int)
+        mask[rs.permutation(N)[:K]] = 1
+        code = _native.Code(_native.default_ctx(), mask)
+        llr = rs.standard_normal((5, N)) * 4
+        for fast in (False, True):
+            info, uh, _ = code.sc_decode(llr, want_uhat=True, fast=fast)
+            assert info.shape == (5, K)
+            for b in range(5):
+                assert np.array_equal(uh[b], oracle.sc_decode(llr[b], mask)), (N, K, fast, b)
+
+
+def test_sc_zero_llr_and_errors():
+    """A zero decision LLR decodes to 0 (the reference blocks on input() and then keeps 0)."""
+    mask = np.ones(8, dtype=int)
+    code = _native.Code(_native.default_ctx(), mask)
+    info, uh, dl = code.sc_decode(np.zeros((1, 8)), want_uhat=True, want_llrs=True)
+    assert not uh.any() and not dl.any()
+    with pytest.raises(_native.PolarError):
+        _native.Code(_native.default_ctx(), np.ones(12))
+    rc = _native.lib().polar_sc_decode(code._h, None, 0, None, None, None, 1, 0, 0)
+    assert rc == -1 and b"llr" in _native.lib().polar_last_error()
+    assert code.sc_decode(np.zeros((0, 8)))[0].shape == (0, 8)
+    pc = PolarCode(8, 4, "dega", 2.0)
+    pc.decoderType = "fano"
+    with pytest.raises(NotImplementedError):
+        pc.decode(np.ones(8))
+
+
+def test_sc_full_size_round_trip():
+    """(1024,512) at the benchmark's batch scale: noiseless and high-SNR frames must decode to the
+    transmitted message; the fused generator + decoder + counter agree with a host-side count."""
+    pc = PolarCode(1024, 512, "dega", 2.0)
+    rs = np.random.RandomState(1)
+    B = 30000
+    msg = rs.randint(0, 2, size=(B, 512))
+    x = pc.polarEncode(msg)
+    llr = (4.0 * (1 - 2 * x)).astype(np.float32)  # noiseless
+    info, _, _ = pc.native.sc_decode(llr, fast=True)
+    assert np.array_equal(info, msg)
+    ch = Channel("BPSK", 6.0, "SNRb", 0.5)
+    llr = pc.native.channel_llr(x, ch.noisePower, 7, 0, np.float32)
+    info, _, _ = pc.native.sc_decode(llr, fast=True)
+    assert np.mean(np.any(info != msg, axis=1)) < 1e-3
+
+
+def test_mc_counters_match_oracle_and_are_chunk_invariant():
+    """Fused Monte-Carlo run in fp64: identical frames (Philox) on both sides; decisions can only differ
+    where device and host libm round a noise sample differently near a decision boundary, so the frame
+    error counts agree to within a few frames in 3000."""
+    mask = pcf.degaBuild(128, 64, 2.0)
+    code = _native.Code(_native.default_ctx(), mask)
+    n0 = Channel("BPSK", 2.0, "SNRb", 0.5).noisePower
+    ref = oracle.mc_run(mask, 0, 1, 1, n0, 2024, 1000, 3000)
+    got = code.mc_run(_native.DEC_SC, 1, np.float64, n0, 2024, 1000, 3000, fast=False)
+    assert int(got[0]) == 3000
+    assert abs(int(got[1]) - int(ref[1])) <= 3 and abs(int(got[2]) - int(ref[2])) <= 60, (got, ref)
+    a = code.mc_run(_native.DEC_SC, 1, np.float32, n0, 2024, 0, 5000)
+    b = code.mc_run(_native.DEC_SC, 1, np.float32, n0, 2024, 0, 2000) + code.mc_run(_native.DEC_SC, 1, np.float32, n0, 2024, 2000, 3000)
+    assert np.array_equal(a, b), "counters must not depend on how the frame range is split"
