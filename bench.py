@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""Benchmark of the polar decode hot path on MI355X.
+
+python bench.py --gpus N --steps K --warmup W
+  N = 1: run directly.  N > 1: launched by torch.distributed.run, one rank per GPU.
+
+Workload (BASELINE.json configs[1]): Polar(1024,512) `dega` code, SC decoding of 10^7 frames per GPU,
+BPSK-AWGN at Eb/N0 = 2 dB, fp32 LLRs already resident in HBM (generated on the device by the library's
+Philox channel before the timed region).  A step = one pass of the decoder over the whole batch
+(decode + extract information bits + count errors); with N > 1 every rank decodes its own 10^7 frames
+(weak scaling, frames keyed by global index) and the three error counters are all-reduced (RCCL) at the
+end of each step.  value = decoded information Mb/s summed over all ranks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "polar-codes_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+
+# Peaks from the MI355X micro-architecture guide: LDS aggregate with every CU streaming ds_read_b64/b128
+# (~150 TB/s; ds_read_b32 reaches ~75 TB/s, ds_write ~38-51 TB/s), HBM3E 8 TB/s.
+LDS_PEAK_GBS = 150000.0
+HBM_PEAK_GBS = 8000.0
+
+
+def lds_bytes_algorithmic(N):
+    """Per-frame LDS traffic of plain SC: N log2 N LLR updates of 2 loads + 1 store (fp32) + 1 partial-sum
+    byte per g, and (N/2) log2 N partial-sum XOR pairs of 2 B in + 2 B out: 14.5 N log2 N bytes."""
+    return 14.5 * N * np.log2(N)
+
+
+def executed_lds_bytes(sched, N, elem=4):
+    """LDS bytes the kernel really moves per frame for a given schedule (fast schedules skip work)."""
+    tot = 0.0
+    n = int(np.log2(N))
+    for w in sched:
+        t, lev = int(w) & 15, (int(w) >> 4) & 31
+        if t in (0, 1):  # F / G: read 2 (from LDS unless top level), write 1
+            h = 1 << (lev - 1)
+            tot += h * elem * (1 if lev == n else 3)
+            if t == 1 and lev - 1 >= 5:
+                tot += h / 8
+        elif t == 5:  # R1: read w values, write w/8 bytes
+            tot += (0 if lev == n else (1 << lev) * elem) + (1 << lev) / 8
+        elif t == 6 and lev - 1 >= 5:  # combine on word arrays
+            tot += 4 * (1 << (lev - 1)) / 8
+        elif t in (2, 3):
+            tot += elem
+    return tot
+
+
+def cpu_baseline(mask, llr_sample, threads):
+    """The CPU oracle's SC decoder (a C restatement of the reference) on the host cores."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import oracle
+
+    oracle.lib()
+    parts = np.array_split(llr_sample, threads)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(lambda a: oracle.sc_decode_batch(a, mask), parts))
+    dt = time.perf_counter() - t0
+    return llr_sample.shape[0] / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=10 ** 7, help="frames per GPU per step")
+    ap.add_argument("--snr", type=float, default=2.0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary SCL / Monte-Carlo legs")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import _native
+    import functions as pcf
+    from channel import Channel
+
+    N, K = 1024, 512
+    mask = pcf.degaBuild(N, K, 2.0)
+    ctx = _native.default_ctx(local)
+    code = _native.Code(ctx, mask)
+    ch = Channel("BPSK", a.snr, "SNRb", K / N)
+    B = a.frames
+    seed = 2024
+    frame0 = rank * B  # global frame index: ranks see disjoint frames
+
+    llr = torch.empty((B, N), dtype=torch.float32, device=dev)
+    info = torch.empty((B, code.Kw), dtype=torch.int32, device=dev)
+    hat = torch.empty((B, code.Kw), dtype=torch.int32, device=dev)
+    counters = torch.zeros(3, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    code.gen_frames_dev(info.data_ptr(), llr.data_ptr(), np.float32, ch.noisePower, seed, frame0, B)
+    ctx.sync()
+    gen_s = time.perf_counter() - t0
+
+    def barrier():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        counters.zero_()
+        torch.cuda.synchronize()
+        code.sc_decode_dev(llr.data_ptr(), np.float32, hat.data_ptr(), B, fast=True)
+        code.count_errors_dev(info.data_ptr(), hat.data_ptr(), B, counters.data_ptr())
+        ctx.sync()
+        if world > 1:
+            dist.all_reduce(counters)
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    cnt = counters.cpu().tolist()
+
+    # live kernel timing: HIP events on the library's launch stream around the decode kernel alone
+    ctx.enable_timing(True)
+    kms = []
+    for _ in range(max(2, a.steps)):
+        code.sc_decode_dev(llr.data_ptr(), np.float32, hat.data_ptr(), B, fast=True)
+        kms.append(code.last_launch()["last_ms"])
+    ctx.enable_timing(False)
+    launch = code.last_launch()
+    k_ms = float(np.mean(kms))
+
+    out = None
+    if rank == 0:
+        frames_total = B * world * a.steps
+        fps = frames_total / dt
+        alg_lds = lds_bytes_algorithmic(N) * B
+        alg_hbm = (4 * N + K / 8) * B
+        sched_fast = _native.schedule_build(mask, True)
+        sched_plain = _native.schedule_build(mask, False)
+        out = {
+            "metric": "decoded info Mb/s, Polar(1024,512) SC, Eb/N0=2dB",
+            "value": fps * K / 1e6,
+            "unit": "Mb/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "Polar(1024,512) dega dSNR=2.0, SC decode, 1e7 frames per GPU, LLRs resident in HBM",
+                       "frames_per_gpu": B, "snr_db": a.snr, "schedule": "fast (rate-0 / rate-1 subtrees short-cut)",
+                       "parallelism": f"frames sharded over {world} GPU(s), counter all-reduce"},
+            "frames_per_s": fps,
+            "fer": cnt[1] / max(cnt[0], 1),
+            "ber": cnt[2] / max(cnt[0] * K, 1),
+            "counters": cnt,
+            "input_gen_s": gen_s,
+            "roofline": {
+                "bound": "lds",
+                "achieved": alg_lds / (k_ms * 1e-3) / 1e9,
+                "peak": LDS_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": alg_lds / (k_ms * 1e-3) / 1e9 / LDS_PEAK_GBS,
+                "traffic": None,
+                "kernel": launch["kernel"],
+                "kernel_ms": k_ms,
+                "algorithmic_bytes_per_frame": lds_bytes_algorithmic(N),
+                "executed_lds_bytes_per_frame": executed_lds_bytes(sched_fast, N),
+                "plain_schedule_lds_bytes_per_frame": executed_lds_bytes(sched_plain, N),
+                "lanes_per_frame": launch["lanes_per_frame"],
+                "grid_blocks": launch["grid_blocks"],
+                "lds_bytes_per_block": launch["lds_bytes_per_block"],
+            },
+            "roofline_hbm": {
+                "bound": "hbm",
+                "achieved": alg_hbm / (k_ms * 1e-3) / 1e9,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": alg_hbm / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_frame": 4 * N + K / 8,
+            },
+        }
+
+    if rank == 0 and world == 1 and not a.no_extras:
+        extras = {}
+        # plain (every-leaf) schedule, same kernel
+        ctx.enable_timing(True)
+        nb = min(B, 1 << 20)
+        code.sc_decode_dev(llr.data_ptr(), np.float32, hat.data_ptr(), nb, fast=False)
+        ms = code.last_launch()["last_ms"]
+        extras["sc_plain_schedule"] = {"frames_per_s": nb / (ms * 1e-3), "info_mbps": nb * K / (ms * 1e-3) / 1e6,
+                                       "lds_GBs_algorithmic": lds_bytes_algorithmic(N) * nb / (ms * 1e-3) / 1e9}
+        # SCL L=8 on a slice of the same LLRs
+        try:
+            nb = min(B, 1 << 18)
+            code.scl_decode_dev(llr.data_ptr(), np.float32, 8, hat.data_ptr(), nb)
+            code.scl_decode_dev(llr.data_ptr(), np.float32, 8, hat.data_ptr(), nb)
+            li = code.last_launch()
+            c2 = torch.zeros(3, dtype=torch.int64, device=dev)
+            code.count_errors_dev(info.data_ptr(), hat.data_ptr(), nb, c2.data_ptr())
+            ctx.sync()
+            c2 = c2.cpu().tolist()
+            extras["scl8"] = {"frames_per_s": nb / (li["last_ms"] * 1e-3), "info_mbps": nb * K / (li["last_ms"] * 1e-3) / 1e6,
+                              "kernel": li["kernel"], "kernel_ms": li["last_ms"], "frames": nb, "fer": c2[1] / nb}
+        except _native.PolarError as e:
+            extras["scl8"] = {"error": str(e)}
+        ctx.enable_timing(False)
+        # fused Monte-Carlo pipeline (generate + decode + count), nothing resident beforehand
+        t0 = time.perf_counter()
+        mc = code.mc_run(_native.DEC_SC, 1, np.float32, ch.noisePower, seed, 0, 1 << 22)
+        mdt = time.perf_counter() - t0
+        extras["mc_pipeline_sc"] = {"frames_per_s": (1 << 22) / mdt, "info_mbps": (1 << 22) * K / mdt / 1e6, "fer": int(mc[1]) / int(mc[0])}
+        out["extras"] = extras
+
+    if rank == 0 and world == 1 and not a.no_cpu:
+        threads = min(16, os.cpu_count() or 1)
+        sample = llr[: 4096 * threads].cpu().numpy()
+        fps_cpu, secs = cpu_baseline(mask, sample, threads)
+        out["cpu_baseline"] = {"value": fps_cpu * K / 1e6, "unit": "Mb/s", "cores": threads, "kind": "port",
+                               "sample": f"{sample.shape[0]} frames of the same LLR batch, oracle SC (C restatement of scDecoder), {secs:.1f} s",
+                               "frames_per_s": fps_cpu,
+                               "reference_python_1core_frames_per_s": 26.4}
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
