@@ -1,0 +1,68 @@
+// Device helpers shared by the SC and SCL decoder kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+__device__ __forceinline__ void wave_sync()
+{
+    // Lanes of one wavefront exchange data through LDS; LDS operations of a wavefront complete in
+    // order, so only the compiler has to be kept from moving accesses across this point.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// min-sum f: sign(a) sign(b) min(|a|,|b|)
+__device__ __forceinline__ float f_minsum(float a, float b)
+{
+    float m = fminf(fabsf(a), fabsf(b));
+    uint32_t s = (__float_as_uint(a) ^ __float_as_uint(b)) & 0x80000000u;
+    return __uint_as_float(__float_as_uint(m) | s);
+}
+__device__ __forceinline__ double f_minsum(double a, double b)
+{
+    double m = fmin(fabs(a), fabs(b));
+    uint64_t s = ((uint64_t)__double_as_longlong(a) ^ (uint64_t)__double_as_longlong(b)) & 0x8000000000000000ull;
+    return __longlong_as_double((long long)((uint64_t)__double_as_longlong(m) | s));
+}
+
+template <int G> __device__ __forceinline__ uint64_t group_ballot(bool pred, int grp)
+{
+    uint64_t b = __ballot(pred);
+    if constexpr (G == 64) return b;
+    return (b >> (grp * G)) & ((1ull << G) - 1ull);
+}
+
+// Packs pred(k), k in [0, count), into 32-bit words and hands them to store(word_index, value).
+// Every lane of the group sees the same packed words.
+template <int G, typename Pred, typename Store>
+__device__ __forceinline__ void pack_bits_group(int count, int sub, int grp, Pred pred, Store store)
+{
+    uint32_t acc = 0;
+    for (int k0 = 0; k0 < count; k0 += G) {
+        int k = k0 + sub;
+        bool p = (k < count) && pred(k);
+        uint64_t gb = group_ballot<G>(p, grp);
+        if constexpr (G >= 32) {
+            store(k0 >> 5, (uint32_t)gb);
+            if (G == 64 && k0 + 32 < count) store((k0 >> 5) + 1, (uint32_t)(gb >> 32));
+        } else {
+            acc |= (uint32_t)gb << (k0 & 31);
+            if (((k0 + G) & 31) == 0 || k0 + G >= count) {
+                store(k0 >> 5, acc);
+                acc = 0;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t butterfly_word(uint32_t x, int n)
+{
+    if (n > 0) x ^= (x >> 1) & 0x55555555u;
+    if (n > 1) x ^= (x >> 2) & 0x33333333u;
+    if (n > 2) x ^= (x >> 4) & 0x0F0F0F0Fu;
+    if (n > 3) x ^= (x >> 8) & 0x00FF00FFu;
+    if (n > 4) x ^= (x >> 16) & 0x0000FFFFu;
+    return x;
+}
+

@@ -1,0 +1,126 @@
+"""GPU parity of the SCL decoder in fp64 against the reference's vectors (whole sorted list, in order,
+path metrics to 1e-12) and the oracle; fp32 mode against the fp32 oracle."""
+import numpy as np
+import pytest
+
+import _native
+import functions as pcf
+from frames import make_frame, pack, unpack
+from oracle import oracle
+from polarCode import PolarCode
+
+pytestmark = pytest.mark.gpu
+
+SCL_TAGS = [("dega", 128, 64, 2, 0.0), ("dega", 128, 64, 2, 2.0), ("dega", 128, 64, 4, 0.0), ("dega", 128, 64, 4, 2.0),
+            ("dega", 128, 64, 8, 0.0), ("dega", 128, 64, 16, 0.0), ("dega", 128, 64, 32, 0.0),
+            ("dega", 1024, 512, 8, 1.0), ("dega", 1024, 512, 8, 2.0),
+            ("rmpolar", 512, 256, 32, 2.0), ("dega", 512, 256, 32, 1.0), ("dega", 512, 256, 32, 2.0)]
+
+
+def test_scl_kat_8_4(golden):
+    g = golden.scl
+    pc = PolarCode(8, 4, "dega", 2.0, listSize=4)
+    pc.decoderType = "SCL"
+    dec = pc.decode(g["kat8_llr"])
+    assert dec.tolist() == [1, 1, 1, 1]
+    pms = [p.pathMetric for p in pc.pathList]
+    np.testing.assert_allclose(pms, [-1.0908631565524596, -3.9727056749214777, -7.787037005675798, -9.229732048891263], rtol=1e-13)
+    assert np.array_equal(pack(np.stack([p.uHat for p in pc.pathList])), g["kat8_uhat"])
+
+
+@pytest.mark.parametrize("cons,N,K,L,snr", SCL_TAGS)
+def test_scl_fp64_matches_reference_vectors(golden, cons, N, K, L, snr):
+    g = golden.scl
+    tag = f"{cons}_{N}_{K}_L{L}_{snr}"
+    pc = PolarCode(N, K, cons, 2.0, listSize=L)
+    seeds = g[f"{tag}_seeds"]
+    frames = [make_frame(pc.polarMask, snr, int(s), oracle.polar_encode) for s in seeds]
+    llr = np.stack([f[2] for f in frames])
+    dec = pc.sclDecoder(llr)
+    assert (g[f"{tag}_gap"] > 1e-9).all()  # no stored frame is sensitive to last-ulp metric differences
+    assert np.array_equal(pack(dec), g[f"{tag}_dec"])
+    for f in range(len(seeds)):
+        got_uh = np.stack([p.uHat for p in pc.pathList[f]])
+        assert np.array_equal(pack(got_uh), g[f"{tag}_uhat"][f]), (tag, f)  # every survivor, in list order
+        ref = g[f"{tag}_pm"][f]
+        pm = pc.pathMetrics[f]
+        assert np.array_equal(np.isinf(pm), np.isinf(ref))
+        fin = np.isfinite(ref)
+        np.testing.assert_allclose(pm[fin], ref[fin], rtol=1e-12)
+        assert int(np.sum(dec[f] != frames[f][0])) == int(g[f"{tag}_biterr"][f])
+    assert [pc.ANV, pc.sortNum, pc.unitCal] == g[f"{tag}_counts"][0].tolist()
+
+
+def test_scl_seeded_kat_1024():
+    pc = PolarCode(1024, 512, "dega", 2.0, listSize=8)
+    msg, x, llr = make_frame(pc.polarMask, 2.0, 2024, oracle.polar_encode)
+    dec = pc.sclDecoder(llr)
+    assert abs(pc.pathList[0].pathMetric - 600.3603000267871) < 1e-9
+    assert (pc.ANV, pc.sortNum, pc.unitCal) == (6788, 510, 64900)
+    assert np.array_equal(dec, msg)
+
+
+@pytest.mark.parametrize("L", [1, 2, 4, 8, 16, 32])
+def test_scl_small_lengths_vs_oracle(L):
+    rs = np.random.RandomState(L)
+    for N in (2, 4, 8, 16, 32, 64, 256):
+        for K in sorted({0, 1, 3 if N > 4 else 1, N // 2, N}):
+            mask = np.zeros(N, dtype=int)
+            mask[rs.permutation(N)[:K]] = 1
+            code = _native.Code(_native.default_ctx(), mask)
+            llr = rs.standard_normal((3, N)) * 2.5
+            info, pm, uh = code.scl_decode(llr, L, want_list=True)
+            for b in range(3):
+                ruh, rpm, _ = oracle.scl_decode(llr[b], mask, L)
+                ns = len(rpm)
+                assert np.array_equal(uh[b, :ns], ruh), (N, K, L, b)
+                np.testing.assert_allclose(pm[b, :ns], rpm, rtol=1e-12, atol=1e-12)
+                assert np.all(np.isneginf(pm[b, ns:])) and not uh[b, ns:].any()
+                assert np.array_equal(info[b], oracle.extract(ruh[0], mask))
+
+
+def test_scl_metric_overflow_gives_minus_inf():
+    """LLR magnitudes beyond 1024 ln 2 make the wrong-decision metric -inf, as in the reference."""
+    mask = np.ones(8, dtype=int)
+    code = _native.Code(_native.default_ctx(), mask)
+    llr = np.array([[900.0, -900.0, 800.0, 1000.0, -750.0, 720.0, 5.0, -3.0]])
+    info, pm, uh = code.scl_decode(llr, 4, want_list=True)
+    ruh, rpm, _ = oracle.scl_decode(llr[0], mask, 4)
+    assert np.array_equal(uh[0], ruh)
+    assert np.array_equal(np.isinf(pm[0]), np.isinf(rpm))
+    np.testing.assert_allclose(pm[0][np.isfinite(rpm)], rpm[np.isfinite(rpm)], rtol=1e-12)
+
+
+def test_scl_fp32_mode_vs_fp32_oracle():
+    """fp32 arithmetic: same algorithm as the fp32 oracle; device exp2f/log2f differ from the host's in
+    the last bits, so only near-tied metrics may order differently: at least 97 % of frames must give
+    identical decoded bits and the frame error counts must agree within 3."""
+    N, K, L = 256, 128, 8
+    mask = pcf.degaBuild(N, K, 2.0)
+    code = _native.Code(_native.default_ctx(), mask)
+    frames = [make_frame(mask, 1.5, 4000 + s, oracle.polar_encode) for s in range(120)]
+    llr = np.stack([f[2] for f in frames]).astype(np.float32)
+    info, _, _ = code.scl_decode(llr, L)
+    same, fe_gpu, fe_cpu = 0, 0, 0
+    for b, fr in enumerate(frames):
+        ruh, _, _ = oracle.scl_decode(llr[b], mask, L)
+        ref = oracle.extract(ruh[0], mask)
+        same += np.array_equal(info[b], ref)
+        fe_gpu += np.any(info[b] != fr[0])
+        fe_cpu += np.any(ref != fr[0])
+    assert same >= 0.97 * len(frames), same
+    assert abs(int(fe_gpu) - int(fe_cpu)) <= 3
+
+
+def test_scl_list_1_equals_sc_and_L_improves_fer():
+    N, K = 256, 128
+    mask = pcf.degaBuild(N, K, 2.0)
+    code = _native.Code(_native.default_ctx(), mask)
+    frames = [make_frame(mask, 1.0, 7000 + s, oracle.polar_encode) for s in range(300)]
+    llr = np.stack([f[2] for f in frames])
+    msg = np.stack([f[0] for f in frames])
+    sc, _, _ = code.sc_decode(llr)
+    l1, _, _ = code.scl_decode(llr, 1)
+    assert np.array_equal(sc, l1)
+    l8, _, _ = code.scl_decode(llr, 8)
+    assert np.any(l8 != msg, axis=1).sum() <= np.any(sc != msg, axis=1).sum()
