@@ -1,0 +1,309 @@
+// Register-resident successive-cancellation decoder (N = 32 .. 1024).
+//
+// Sixteen lanes (one DPP row) decode one frame, four frames per wavefront.  Element k of a tree level
+// lives in lane k mod 16, so for every level of width >= 32 the pair (k, k + width/2) that f and g
+// combine sits in the SAME lane: those levels are plain per-lane register arithmetic on a slice of
+// N/16 values per lane, statically indexed (the level is dispatched through a switch so every array
+// index is a compile-time constant).  Partial sums are sliced the same way, one bit per element,
+// level l occupying bits [2^(l-4), 2^(l-3)) of a 64-bit register per plane; combining two children is
+// (xl ^ xr) | (xr << c) in each lane.
+// The bottom four levels (a 16-leaf subtree, one LLR per lane) are decoded with DPP row rotations:
+// after each f/g step the values are replicated with half the period, every lane runs the same
+// instruction stream and keeps the partial-sum bit of "its" element.
+// No LDS is used on the decoding path; the channel LLRs are read from global memory by the two
+// top-level operations, and LDS only stages 8 bytes per lane for the final gather of the info bits.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "decode_common.h"
+#include "polar_internal.h"
+
+// ---- DPP row rotation: lane i of a 16-lane row reads lane (i - R) mod 16 ---------------------------
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v)
+{
+    uint64_t b = (uint64_t)__double_as_longlong(v);
+    uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, 0xF, 0xF, false);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, 0xF, 0xF, false);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_mov_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+// partner exchange for a period-P replicated vector: rotate by P/2
+template <int P, typename T> __device__ __forceinline__ T partner(T v)
+{
+    if constexpr (P == 16) return dpp_mov<0x128>(v);       // row_ror:8
+    else if constexpr (P == 8) return dpp_mov<0x124>(v);   // row_ror:4
+    else if constexpr (P == 4) return dpp_mov<0x4E>(v);    // quad_perm:[2,3,0,1]
+    else return dpp_mov<0xB1>(v);                          // quad_perm:[1,0,3,2]
+}
+
+template <typename T> __device__ __forceinline__ T g_apply(T a, T b, uint32_t bit) { return bit ? b - a : b + a; }
+
+// Decodes a node of P leaves whose P LLRs are replicated with period P over the row.
+// mask: P bits (wave-uniform), bit i = leaf i carries information.  Returns the node's partial-sum bit of
+// element (sub mod P).  SHORT enables the rate-0 / rate-1 short-cuts (same decisions).
+template <int P, bool SHORT, typename T> __device__ __forceinline__ uint32_t sub_node(T v, uint32_t mask, int sub)
+{
+    if constexpr (P == 1) {
+        return (mask & 1u) ? (v < (T)0 ? 1u : 0u) : 0u;
+    } else {
+        constexpr uint32_t FULL = (1u << P) - 1u, HALF = (1u << (P / 2)) - 1u;
+        if (SHORT) {
+            if (mask == 0u) return 0u;
+            if (mask == FULL) return v < (T)0 ? 1u : 0u;
+        }
+        const T o = partner<P>(v);
+        const bool up = (sub & (P / 2)) != 0;
+        const T lo = up ? o : v, hi = up ? v : o;
+        const T vl = f_minsum(v, o);
+        const uint32_t xl = sub_node<P / 2, SHORT>(vl, mask & HALF, sub);
+        const T vr = g_apply(lo, hi, xl);
+        const uint32_t xr = sub_node<P / 2, SHORT>(vr, mask >> (P / 2), sub);
+        return up ? xr : (xl ^ xr);
+    }
+}
+
+typedef uint64_t ps_t;
+
+template <typename T, int NLOG> struct RegDec {
+    static constexpr int S = 1 << (NLOG - 4);  // slice length per lane
+    T R[S];                                    // level l (4 <= l < NLOG): 2^(l-4) values at offset 2^(l-4)
+    ps_t ps0, ps1;                             // partial sums (plane 0 / 1), same offsets, one bit per value
+    ps_t root;
+
+    // f or g from level LEV to LEV-1 (5 <= LEV <= NLOG); the top level reads the channel from memory
+    template <int LEV, bool IS_G> __device__ __forceinline__ void step(const T *chan_lane)
+    {
+        constexpr int c = 1 << (LEV - 5);
+#pragma unroll
+        for (int j = 0; j < c; j++) {
+            T a, b;
+            if constexpr (LEV == NLOG) {
+                a = chan_lane[16 * j];
+                b = chan_lane[16 * (j + c)];
+            } else {
+                a = R[2 * c + j];
+                b = R[3 * c + j];
+            }
+            if constexpr (IS_G) R[c + j] = g_apply(a, b, (uint32_t)(ps0 >> (c + j)) & 1u);
+            else R[c + j] = f_minsum(a, b);
+        }
+    }
+    template <int LEV> __device__ __forceinline__ void combine(int plane)
+    {
+        constexpr int c = 1 << (LEV - 5);
+        const ps_t m = (c >= 64) ? ~(ps_t)0 : (((ps_t)1 << c) - 1);
+        const ps_t xl = (ps0 >> c) & m, xr = (ps1 >> c) & m;
+        if constexpr (LEV == NLOG) {
+            root = (xl ^ xr) | (c >= 64 ? 0 : (xr << c));
+        } else {
+            const ps_t x = (xl ^ xr) | (xr << c);
+            const ps_t m2 = (((ps_t)1 << (2 * c)) - 1) << (2 * c);
+            if (plane) ps1 = (ps1 & ~m2) | (x << (2 * c));
+            else ps0 = (ps0 & ~m2) | (x << (2 * c));
+        }
+    }
+    template <int LEV> __device__ __forceinline__ void rate0(int plane)
+    {
+        constexpr int c = 1 << (LEV - 4);
+        const ps_t m2 = (((ps_t)1 << c) - 1) << c;
+        if (plane) ps1 &= ~m2;
+        else ps0 &= ~m2;
+    }
+    template <int LEV> __device__ __forceinline__ void rate1(int plane)
+    {
+        constexpr int c = 1 << (LEV - 4);
+        ps_t x = 0;
+#pragma unroll
+        for (int j = 0; j < c; j++) x |= (ps_t)(R[c + j] < (T)0 ? 1u : 0u) << j;
+        const ps_t m2 = (((ps_t)1 << c) - 1) << c;
+        if (plane) ps1 = (ps1 & ~m2) | (x << c);
+        else ps0 = (ps0 & ~m2) | (x << c);
+    }
+};
+
+// Node classes per tree level (bit i of level l = node i of that level, l = 4 .. 10 -> index l-4):
+// r0 = every leaf frozen, r1 = every leaf information.  In plain (non-fast) mode both are all zero.
+struct NodeClasses {
+    uint64_t r0[7];
+    uint64_t r1[7];
+};
+
+// A mixed node at level LEV >= 5, index idx within its level.  The two children are visited by a
+// two-trip loop that is deliberately NOT unrolled: every level's code then exists exactly once in the
+// program (F, G, rate-0, rate-1, combine), the recursion is a fixed nest of NLOG-4 loops, and the
+// register array keeps fixed homes.
+template <int LEV, int NLOG, bool FAST, typename T>
+__device__ __forceinline__ void decode_node(RegDec<T, NLOG> &d, const NodeClasses &nc, const uint32_t *__restrict__ maskw,
+                                            const T *chan_lane, uint32_t idx, int plane, int sub)
+{
+#pragma nounroll
+    for (uint32_t h = 0; h < 2; h++) {
+        if (h == 0) d.template step<LEV, false>(chan_lane);
+        else d.template step<LEV, true>(chan_lane);
+        const uint32_t cidx = 2 * idx + h;
+        const bool is0 = FAST && ((nc.r0[LEV - 5] >> cidx) & 1ull);
+        const bool is1 = FAST && ((nc.r1[LEV - 5] >> cidx) & 1ull);
+        if (is0) {
+            d.template rate0<LEV - 1>((int)h);
+        } else if (is1) {
+            d.template rate1<LEV - 1>((int)h);
+        } else {
+            if constexpr (LEV - 1 == 4) {
+                const uint32_t m16 = (maskw[cidx >> 1] >> (16 * (cidx & 1))) & 0xFFFFu;
+                const uint32_t x = sub_node<16, FAST>(d.R[1], m16, sub);
+                if (h) d.ps1 = (d.ps1 & ~(ps_t)2) | ((ps_t)x << 1);
+                else d.ps0 = (d.ps0 & ~(ps_t)2) | ((ps_t)x << 1);
+            } else {
+                decode_node<LEV - 1, NLOG, FAST>(d, nc, maskw, chan_lane, cidx, (int)h, sub);
+            }
+        }
+    }
+    d.template combine<LEV>(plane);
+}
+
+template <typename T, int NLOG, bool FAST>
+__global__ void __launch_bounds__(64) sc_reg_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, NodeClasses nc,
+                                                    const uint32_t *__restrict__ Asl, uint32_t *__restrict__ info_hat, int64_t B,
+                                                    int K, int Kw)
+{
+    __shared__ uint32_t stage[4 * 16 * 2];  // per frame: 16 lanes x 64-bit slice of u_hat
+    constexpr int N = 1 << NLOG;
+    const int lane = threadIdx.x;
+    const int grp = lane >> 4;
+    const int sub = lane & 15;
+    RegDec<T, NLOG> d;
+
+    for (int64_t f0 = (int64_t)blockIdx.x * 4; f0 < B; f0 += (int64_t)gridDim.x * 4) {
+        const int64_t f = f0 + grp;
+        const bool active = f < B;
+        const int64_t fc = active ? f : B - 1;
+        const T *chan_lane = llr + fc * N + sub;
+        d.ps0 = d.ps1 = 0;
+        d.root = 0;
+        decode_node<NLOG, NLOG, FAST>(d, nc, maskw, chan_lane, 0u, 0, sub);
+
+        // u_hat = x_hat F^{(x)n} on the sliced layout: element k = sub + 16 j is bit j of lane sub.
+        ps_t u = d.root;
+        // stages 4 .. NLOG-1 pair (j, j + 2^(s-4)) inside a lane
+        if constexpr (NLOG > 4) u ^= (u >> 1) & 0x5555555555555555ull;
+        if constexpr (NLOG > 5) u ^= (u >> 2) & 0x3333333333333333ull;
+        if constexpr (NLOG > 6) u ^= (u >> 4) & 0x0F0F0F0F0F0F0F0Full;
+        if constexpr (NLOG > 7) u ^= (u >> 8) & 0x00FF00FF00FF00FFull;
+        if constexpr (NLOG > 8) u ^= (u >> 16) & 0x0000FFFF0000FFFFull;
+        if constexpr (NLOG > 9) u ^= (u >> 32) & 0x00000000FFFFFFFFull;
+        // stages 0 .. 3 pair lanes (l, l + 2^s) of the row: row_shl:n makes lane i read lane i + n
+        {
+            uint32_t lo = (uint32_t)u, hi = (uint32_t)(u >> 32);
+            uint32_t t;
+            t = dpp_mov_u32<0x101>(lo); lo ^= (sub & 1) ? 0u : t; t = dpp_mov_u32<0x101>(hi); hi ^= (sub & 1) ? 0u : t;
+            t = dpp_mov_u32<0x102>(lo); lo ^= (sub & 2) ? 0u : t; t = dpp_mov_u32<0x102>(hi); hi ^= (sub & 2) ? 0u : t;
+            t = dpp_mov_u32<0x104>(lo); lo ^= (sub & 4) ? 0u : t; t = dpp_mov_u32<0x104>(hi); hi ^= (sub & 4) ? 0u : t;
+            t = dpp_mov_u32<0x108>(lo); lo ^= (sub & 8) ? 0u : t; t = dpp_mov_u32<0x108>(hi); hi ^= (sub & 8) ? 0u : t;
+            stage[lane * 2] = lo;
+            stage[lane * 2 + 1] = hi;
+        }
+        wave_sync();
+        if (info_hat) {
+            uint32_t *dst = info_hat + fc * Kw;
+            const uint32_t *mine = stage + grp * 32;
+            pack_bits_group<16>(
+                K, sub, grp,
+                [&](int k) {
+                    uint32_t a = Asl[k];  // (lane << 6) | bit
+                    return ((mine[(a >> 6) * 2 + ((a >> 5) & 1u)] >> (a & 31u)) & 1u) != 0u;
+                },
+                [&](int wi, uint32_t v) {
+                    if (sub == 0 && active) dst[wi] = v;
+                });
+            if (K == 0 && sub == 0 && active) dst[0] = 0u;
+        }
+        wave_sync();
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+static NodeClasses classify_nodes(const polar_code *c, bool fast)
+{
+    NodeClasses nc;
+    memset(&nc, 0, sizeof(nc));
+    if (!fast) return nc;
+    for (int lev = 4; lev <= c->n && lev <= 10; lev++) {
+        const int w = 1 << lev;
+        for (int i = 0; i < (c->N >> lev); i++) {
+            int ninfo = 0;
+            for (int k = 0; k < w; k++) ninfo += c->mask[(size_t)i * w + k];
+            if (ninfo == 0) nc.r0[lev - 4] |= 1ull << i;
+            if (ninfo == w) nc.r1[lev - 4] |= 1ull << i;
+        }
+    }
+    return nc;
+}
+
+bool sc_reg_supported(const polar_code *c, int dtype, const void *u_hat, const void *dec_llr)
+{
+    if (u_hat || dec_llr) return false;
+    if (c->n < 5 || c->n > 10) return false;
+    if (c->K == 0 || c->K == c->N) return false;  // root would be a rate-0 / rate-1 node
+    if (dtype != POLAR_F32) return false;  // fp64 (parity mode) runs on the LDS-staged kernel
+    const char *e = getenv("POLAR_SC_KERNEL");
+    if (e && e[0] == 'l') return false;  // "lds": force the LDS-staged kernel
+    return true;
+}
+
+template <typename T, int NLOG, bool FAST> static int launch_reg_t(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B)
+{
+    polar_ctx *ctx = c->ctx;
+    const NodeClasses nc = classify_nodes(c, FAST);
+    auto kern = sc_reg_kernel<T, NLOG, FAST>;
+    int occ = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, 0));
+    if (occ < 1) occ = 1;
+    int64_t need = (B + 3) / 4;
+    int64_t grid = std::min<int64_t>(need, (int64_t)ctx->num_cus * occ * 8);
+    LaunchTimer tm(ctx);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), 0, ctx->stream, (const T *)llr, (const uint32_t *)c->d_maskw, nc,
+                       (const uint32_t *)c->d_Asl, info_hat, B, c->K, c->Kw);
+    HIP_TRY(hipGetLastError());
+    float ms = tm.stop();
+    snprintf(c->last.kernel, sizeof(c->last.kernel), "sc_reg_kernel<%s,%d>%s", sizeof(T) == 4 ? "float" : "double", NLOG,
+             FAST ? "/fast" : "");
+    c->last.lanes_per_frame = 16;
+    c->last.lds_bytes_per_block = 512;
+    c->last.block_threads = 64;
+    c->last.grid_blocks = (int)grid;
+    c->last.last_ms = ms;
+    return POLAR_OK;
+}
+
+template <typename T> static int launch_reg_n(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, int flags)
+{
+    switch (c->n) {
+    case 5: return (flags & POLAR_SC_FAST) ? launch_reg_t<T, 5, true>(c, llr, info_hat, B) : launch_reg_t<T, 5, false>(c, llr, info_hat, B);
+    case 6: return (flags & POLAR_SC_FAST) ? launch_reg_t<T, 6, true>(c, llr, info_hat, B) : launch_reg_t<T, 6, false>(c, llr, info_hat, B);
+    case 7: return (flags & POLAR_SC_FAST) ? launch_reg_t<T, 7, true>(c, llr, info_hat, B) : launch_reg_t<T, 7, false>(c, llr, info_hat, B);
+    case 8: return (flags & POLAR_SC_FAST) ? launch_reg_t<T, 8, true>(c, llr, info_hat, B) : launch_reg_t<T, 8, false>(c, llr, info_hat, B);
+    case 9: return (flags & POLAR_SC_FAST) ? launch_reg_t<T, 9, true>(c, llr, info_hat, B) : launch_reg_t<T, 9, false>(c, llr, info_hat, B);
+    case 10: return (flags & POLAR_SC_FAST) ? launch_reg_t<T, 10, true>(c, llr, info_hat, B) : launch_reg_t<T, 10, false>(c, llr, info_hat, B);
+    default: polar_set_error("register SC kernel: unsupported length"); return POLAR_EUNSUPPORTED;
+    }
+}
+
+int launch_sc_reg(polar_code *c, const void *llr, int dtype, uint32_t *info_hat, int64_t B, int flags)
+{
+    if (B == 0) return POLAR_OK;
+    if (dtype != POLAR_F32) {
+        polar_set_error("register SC kernel: fp32 only");
+        return POLAR_EUNSUPPORTED;
+    }
+    return launch_reg_n<float>(c, llr, info_hat, B, flags);
+}

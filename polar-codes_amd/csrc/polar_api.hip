@@ -178,7 +178,11 @@ extern "C" int polar_code_create(polar_ctx *ctx, int N, const uint8_t *mask, pol
     c->Kw = std::max(1, (c->K + 31) / 32);
     c->sched[0] = build_schedule(c->mask.data(), N, false);
     c->sched[1] = build_schedule(c->mask.data(), N, true);
+    std::vector<uint32_t> Asl;
+    for (uint32_t pos : A) Asl.push_back(((pos & 15u) << 6) | (pos >> 4));
     if (A.empty()) A.push_back(0);
+    if (Asl.empty()) Asl.push_back(0);
+
     auto up = [&](uint32_t **dst, const std::vector<uint32_t> &v) -> int {
         HIP_TRY(hipMalloc((void **)dst, v.size() * sizeof(uint32_t)));
         HIP_TRY(hipMemcpy(*dst, v.data(), v.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -186,7 +190,7 @@ extern "C" int polar_code_create(polar_ctx *ctx, int N, const uint8_t *mask, pol
     };
     int rc;
     if ((rc = up(&c->d_maskw, maskw)) || (rc = up(&c->d_rank, rank)) || (rc = up(&c->d_A, A)) ||
-        (rc = up(&c->d_sched[0], c->sched[0])) || (rc = up(&c->d_sched[1], c->sched[1]))) {
+        (rc = up(&c->d_sched[0], c->sched[0])) || (rc = up(&c->d_sched[1], c->sched[1])) || (rc = up(&c->d_Asl, Asl))) {
         polar_code_destroy(c);
         return rc;
     }
@@ -199,7 +203,7 @@ extern "C" int polar_code_destroy(polar_code *c)
     if (!c) return POLAR_OK;
     (void)hipSetDevice(c->ctx->device);
     (void)hipStreamSynchronize(c->ctx->stream);
-    uint32_t *ps[] = {c->d_maskw, c->d_rank, c->d_A, c->d_sched[0], c->d_sched[1]};
+    uint32_t *ps[] = {c->d_maskw, c->d_rank, c->d_A, c->d_sched[0], c->d_sched[1], c->d_sched[2], c->d_sched[3], c->d_Asl};
     for (uint32_t *p : ps)
         if (p) (void)hipFree(p);
     delete c;
@@ -209,7 +213,7 @@ extern "C" int polar_code_n(const polar_code *c) { return c ? c->N : 0; }
 extern "C" int polar_code_k(const polar_code *c) { return c ? c->K : 0; }
 extern "C" int polar_code_schedule_len(const polar_code *c, int which)
 {
-    return (c && (which == 0 || which == 1)) ? (int)c->sched[which].size() : 0;
+    return (c && which >= 0 && which < 4) ? (int)c->sched[which].size() : 0;
 }
 extern "C" int polar_last_launch(polar_code *c, polar_launch_info *out)
 {

@@ -51,6 +51,7 @@ static inline uint32_t make_op(uint32_t type, uint32_t level, uint32_t plane, ui
 #define OP_LEAFIDX(w) ((w) >> 12)
 
 std::vector<uint32_t> build_schedule(const uint8_t *mask, int N, bool fast);
+std::vector<uint32_t> build_schedule_reg(const uint8_t *mask, int N, bool fast);
 
 // ---- grow-only device buffer ------------------------------------------------------------------
 struct DevBuf {
@@ -77,12 +78,13 @@ struct polar_code {
     int N = 0, n = 0, K = 0;
     int Nw = 0, Kw = 0;  // words per frame (codeword / info)
     std::vector<uint8_t> mask;
-    std::vector<uint32_t> sched[2];  // 0 = plain, 1 = fast
+    std::vector<uint32_t> sched[4];  // 0 = plain, 1 = fast; 2 = fast, 3 = plain for the register kernel
     // device tables
     uint32_t *d_maskw = nullptr;   // Nw words
     uint32_t *d_rank = nullptr;    // Nw words: info bits before word w
     uint32_t *d_A = nullptr;       // K info positions, ascending
-    uint32_t *d_sched[2] = {nullptr, nullptr};
+    uint32_t *d_sched[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t *d_Asl = nullptr;     // K entries: (lane << 6) | bit of each info position in the sliced layout
     polar_launch_info last{};
 };
 
@@ -96,6 +98,8 @@ int launch_gen_frames(polar_code *c, uint32_t *info, void *llr, int dtype, doubl
                       uint64_t frame0, int64_t B);
 int launch_sc_decode(polar_code *c, const void *llr, int dtype, uint32_t *info_hat, uint32_t *u_hat,
                      void *dec_llr, int64_t B, int flags);
+bool sc_reg_supported(const polar_code *c, int dtype, const void *u_hat, const void *dec_llr);
+int launch_sc_reg(polar_code *c, const void *llr, int dtype, uint32_t *info_hat, int64_t B, int flags);
 int launch_scl_decode(polar_code *c, const void *llr, int dtype, int L, uint32_t *info_hat, double *pm,
                       uint32_t *u_hat_all, int64_t B);
 int launch_count_errors(polar_code *c, const uint32_t *info, const uint32_t *hat, int64_t B, uint64_t *counters);

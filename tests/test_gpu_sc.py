@@ -134,3 +134,45 @@ def test_mc_counters_match_oracle_and_are_chunk_invariant():
     a = code.mc_run(_native.DEC_SC, 1, np.float32, n0, 2024, 0, 5000)
     b = code.mc_run(_native.DEC_SC, 1, np.float32, n0, 2024, 0, 2000) + code.mc_run(_native.DEC_SC, 1, np.float32, n0, 2024, 2000, 3000)
     assert np.array_equal(a, b), "counters must not depend on how the frame range is split"
+
+
+@pytest.mark.parametrize("N", [32, 64, 128, 256, 512, 1024])
+def test_sc_register_kernel_vs_oracle_fp32(N):
+    """The register-resident kernel (fp32, info bits only) against the fp32 oracle, bit-exact, for every
+    supported length, ragged batches, plain and fast schedules, several rates."""
+    rs = np.random.RandomState(N)
+    for K in sorted({1, N // 4, N // 2, (3 * N) // 4, N - 1}):
+        mask = pcf.degaBuild(N, K, 2.0)
+        code = _native.Code(_native.default_ctx(), mask)
+        B = 23
+        frames = [make_frame(mask, 1.0 + 2.0 * rs.rand(), int(rs.randint(1 << 30)), oracle.polar_encode) for _ in range(B)]
+        llr = np.stack([f[2] for f in frames]).astype(np.float32)
+        ref = np.stack([oracle.extract(oracle.sc_decode(llr[b], mask), mask) for b in range(B)])
+        for fast in (True, False):
+            info, _, _ = code.sc_decode(llr, fast=fast)
+            assert code.last_launch()["kernel"].startswith("sc_reg_kernel"), code.last_launch()
+            assert np.array_equal(info, ref), (N, K, fast)
+    # random (non-nested) rate profiles exercise every 16-leaf subtree pattern
+    for trial in range(4):
+        mask = (rs.rand(N) < 0.5).astype(int)
+        mask[0], mask[-1] = 0, 1
+        code = _native.Code(_native.default_ctx(), mask)
+        llr = (rs.standard_normal((9, N)) * 3).astype(np.float32)
+        ref = np.stack([oracle.extract(oracle.sc_decode(llr[b], mask), mask) for b in range(9)])
+        for fast in (True, False):
+            info, _, _ = code.sc_decode(llr, fast=fast)
+            assert np.array_equal(info, ref), (N, trial, fast)
+
+
+def test_sc_register_and_lds_kernels_agree(monkeypatch):
+    pc = PolarCode(1024, 512, "dega", 2.0)
+    ch = Channel("BPSK", 1.5, "SNRb", 0.5)
+    rs = np.random.RandomState(2)
+    x = pc.polarEncode(rs.randint(0, 2, size=(4001, 512)))
+    llr = pc.native.channel_llr(x, ch.noisePower, 3, 0, np.float32)
+    a, _, _ = pc.native.sc_decode(llr, fast=True)
+    assert pc.native.last_launch()["kernel"].startswith("sc_reg_kernel")
+    monkeypatch.setenv("POLAR_SC_KERNEL", "lds")
+    b, _, _ = pc.native.sc_decode(llr, fast=True)
+    assert pc.native.last_launch()["kernel"].startswith("sc_decode_kernel")
+    assert np.array_equal(a, b)

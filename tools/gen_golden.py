@@ -283,7 +283,7 @@ def _curve_worker(args):
     pc = make_code(polarCode, functions, N, K, cons, ds)
     pc.L = L
     ch = channel.Channel("BPSK", snr, "SNRb", K / N)
-    fe = be = 0
+    fe = be = be2 = 0
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         for f in range(nfr):
@@ -291,8 +291,9 @@ def _curve_worker(args):
             d = pc.scDecoder(llr) if dec == "sc" else pc.sclDecoder(llr)
             e = int(np.sum(np.abs(msg - d)))
             be += e
+            be2 += e * e
             fe += e > 0
-    return (nfr, fe, be)
+    return (nfr, fe, be, be2)
 
 
 def gen_curves(functions, polarCode, channel):
@@ -317,7 +318,8 @@ def gen_curves(functions, polarCode, channel):
                 fr = sum(r[0] for r in res)
                 fe = sum(r[1] for r in res)
                 be = sum(r[2] for r in res)
-                rows.append((snr, fr, fe, be))
+                be2 = sum(r[3] for r in res)
+                rows.append((snr, fr, fe, be, be2))  # be2 = sum of squared per-frame bit errors
                 print(f"curve {tag} {snr} dB: frames {fr} fe {fe} be {be} ({time.time()-t0:.0f}s)", flush=True)
             out[tag] = np.array(rows, dtype=np.float64)
             np.savez_compressed(os.path.join(OUT, "curves.npz"), **out)
