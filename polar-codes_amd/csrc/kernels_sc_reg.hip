@@ -48,27 +48,59 @@ template <int P, typename T> __device__ __forceinline__ T partner(T v)
 
 template <typename T> __device__ __forceinline__ T g_apply(T a, T b, uint32_t bit) { return bit ? b - a : b + a; }
 
+// ---- fp32 helpers that keep the bottom-subtree bit logic on the vector ALU -------------------------
+// (the scalar ALU is shared by the four SIMDs of a CU; boolean algebra on lane masks would land there)
+__device__ __forceinline__ uint32_t pin(uint32_t x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+__device__ __forceinline__ float minabs(float a, float b)
+{
+    float m;
+    asm("v_min_f32 %0, |%1|, |%2|" : "=v"(m) : "v"(a), "v"(b));
+    return m;
+}
+// sign(a) sign(b) min(|a|,|b|) in three vector instructions
+__device__ __forceinline__ float f_fast(float a, float b)
+{
+    uint32_t s = __float_as_uint(a) ^ __float_as_uint(b);
+    return __uint_as_float((s & 0x80000000u) | __float_as_uint(minabs(a, b)));
+}
+__device__ __forceinline__ double f_fast(double a, double b) { return f_minsum(a, b); }
+// b + (bit ? -a : a) with the bit as an integer 0/1
+__device__ __forceinline__ float g_fast(float a, float b, uint32_t bit) { return b + __uint_as_float(__float_as_uint(a) ^ (bit << 31)); }
+__device__ __forceinline__ double g_fast(double a, double b, uint32_t bit) { return g_apply(a, b, bit); }
+
+// Lane constants of the replicated butterfly: for period P, lanes whose element index is in the upper half.
+struct RowConst {
+    uint32_t lowmask[4];  // P = 16, 8, 4, 2: all-ones when (sub & P/2) == 0
+    bool up[4];
+};
+
 // Decodes a node of P leaves whose P LLRs are replicated with period P over the row.
 // mask: P bits (wave-uniform), bit i = leaf i carries information.  Returns the node's partial-sum bit of
-// element (sub mod P).  SHORT enables the rate-0 / rate-1 short-cuts (same decisions).
-template <int P, bool SHORT, typename T> __device__ __forceinline__ uint32_t sub_node(T v, uint32_t mask, int sub)
+// element (sub mod P) as an integer 0/1.  SHORT enables the rate-0 / rate-1 short-cuts at P = 8 and 4
+// (same decisions).
+template <int P, bool SHORT, typename T> __device__ __forceinline__ uint32_t sub_node(T v, uint32_t mask, const RowConst &rc)
 {
     if constexpr (P == 1) {
-        return (mask & 1u) ? (v < (T)0 ? 1u : 0u) : 0u;
+        const uint32_t neg = pin(v < (T)0 ? 1u : 0u);
+        return neg & mask;  // mask is the single (uniform) info bit
     } else {
         constexpr uint32_t FULL = (1u << P) - 1u, HALF = (1u << (P / 2)) - 1u;
-        if (SHORT) {
+        constexpr int I = P == 16 ? 0 : P == 8 ? 1 : P == 4 ? 2 : 3;
+        if (SHORT && P >= 4 && P < 16) {
             if (mask == 0u) return 0u;
-            if (mask == FULL) return v < (T)0 ? 1u : 0u;
+            if (mask == FULL) return pin(v < (T)0 ? 1u : 0u);
         }
         const T o = partner<P>(v);
-        const bool up = (sub & (P / 2)) != 0;
-        const T lo = up ? o : v, hi = up ? v : o;
-        const T vl = f_minsum(v, o);
-        const uint32_t xl = sub_node<P / 2, SHORT>(vl, mask & HALF, sub);
-        const T vr = g_apply(lo, hi, xl);
-        const uint32_t xr = sub_node<P / 2, SHORT>(vr, mask >> (P / 2), sub);
-        return up ? xr : (xl ^ xr);
+        const T lo = rc.up[I] ? o : v, hi = rc.up[I] ? v : o;
+        const T vl = f_fast(v, o);
+        const uint32_t xl = sub_node<P / 2, SHORT>(vl, mask & HALF, rc);
+        const T vr = g_fast(lo, hi, xl);
+        const uint32_t xr = sub_node<P / 2, SHORT>(vr, (mask >> (P / 2)) & HALF, rc);
+        return xr ^ (xl & rc.lowmask[I]);
     }
 }
 
@@ -94,8 +126,8 @@ template <typename T, int NLOG> struct RegDec {
                 a = R[2 * c + j];
                 b = R[3 * c + j];
             }
-            if constexpr (IS_G) R[c + j] = g_apply(a, b, (uint32_t)(ps0 >> (c + j)) & 1u);
-            else R[c + j] = f_minsum(a, b);
+            if constexpr (IS_G) R[c + j] = g_fast(a, b, (uint32_t)(ps0 >> (c + j)) & 1u);
+            else R[c + j] = f_fast(a, b);
         }
     }
     template <int LEV> __device__ __forceinline__ void combine(int plane)
@@ -143,8 +175,8 @@ struct NodeClasses {
 // program (F, G, rate-0, rate-1, combine), the recursion is a fixed nest of NLOG-4 loops, and the
 // register array keeps fixed homes.
 template <int LEV, int NLOG, bool FAST, typename T>
-__device__ __forceinline__ void decode_node(RegDec<T, NLOG> &d, const NodeClasses &nc, const uint32_t *__restrict__ maskw,
-                                            const T *chan_lane, uint32_t idx, int plane, int sub)
+__device__ __forceinline__ void decode_node(RegDec<T, NLOG> &d, const NodeClasses &nc, uint32_t maskv, const T *chan_lane,
+                                            uint32_t idx, int plane, const RowConst &rc)
 {
 #pragma nounroll
     for (uint32_t h = 0; h < 2; h++) {
@@ -159,12 +191,14 @@ __device__ __forceinline__ void decode_node(RegDec<T, NLOG> &d, const NodeClasse
             d.template rate1<LEV - 1>((int)h);
         } else {
             if constexpr (LEV - 1 == 4) {
-                const uint32_t m16 = (maskw[cidx >> 1] >> (16 * (cidx & 1))) & 0xFFFFu;
-                const uint32_t x = sub_node<16, FAST>(d.R[1], m16, sub);
+                // lane i of maskv holds word i of the rate profile; the index is wave-uniform
+                const uint32_t mw = (uint32_t)__builtin_amdgcn_readlane((int)maskv, (int)(cidx >> 1));
+                const uint32_t m16 = (mw >> (16 * (cidx & 1))) & 0xFFFFu;
+                const uint32_t x = sub_node<16, FAST>(d.R[1], m16, rc);
                 if (h) d.ps1 = (d.ps1 & ~(ps_t)2) | ((ps_t)x << 1);
                 else d.ps0 = (d.ps0 & ~(ps_t)2) | ((ps_t)x << 1);
             } else {
-                decode_node<LEV - 1, NLOG, FAST>(d, nc, maskw, chan_lane, cidx, (int)h, sub);
+                decode_node<LEV - 1, NLOG, FAST>(d, nc, maskv, chan_lane, cidx, (int)h, rc);
             }
         }
     }
@@ -172,7 +206,7 @@ __device__ __forceinline__ void decode_node(RegDec<T, NLOG> &d, const NodeClasse
 }
 
 template <typename T, int NLOG, bool FAST>
-__global__ void __launch_bounds__(64) sc_reg_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, NodeClasses nc,
+__global__ void __launch_bounds__(64, 4) sc_reg_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, NodeClasses nc,
                                                     const uint32_t *__restrict__ Asl, uint32_t *__restrict__ info_hat, int64_t B,
                                                     int K, int Kw)
 {
@@ -182,6 +216,13 @@ __global__ void __launch_bounds__(64) sc_reg_kernel(const T *__restrict__ llr, c
     const int grp = lane >> 4;
     const int sub = lane & 15;
     RegDec<T, NLOG> d;
+    RowConst rc;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        rc.up[i] = (sub & (8 >> i)) != 0;
+        rc.lowmask[i] = rc.up[i] ? 0u : 0xFFFFFFFFu;
+    }
+    const uint32_t maskv = maskw[(lane & 31) < (N / 32) ? (lane & 31) : 0];
 
     for (int64_t f0 = (int64_t)blockIdx.x * 4; f0 < B; f0 += (int64_t)gridDim.x * 4) {
         const int64_t f = f0 + grp;
@@ -190,7 +231,7 @@ __global__ void __launch_bounds__(64) sc_reg_kernel(const T *__restrict__ llr, c
         const T *chan_lane = llr + fc * N + sub;
         d.ps0 = d.ps1 = 0;
         d.root = 0;
-        decode_node<NLOG, NLOG, FAST>(d, nc, maskw, chan_lane, 0u, 0, sub);
+        decode_node<NLOG, NLOG, FAST>(d, nc, maskv, chan_lane, 0u, 0, rc);
 
         // u_hat = x_hat F^{(x)n} on the sliced layout: element k = sub + 16 j is bit j of lane sub.
         ps_t u = d.root;
