@@ -24,10 +24,25 @@ for p in (ROOT, os.path.join(ROOT, "polar-codes_amd")):
 
 import numpy as np
 
-# Peaks from the MI355X micro-architecture guide: LDS aggregate with every CU streaming ds_read_b64/b128
-# (~150 TB/s; ds_read_b32 reaches ~75 TB/s, ds_write ~38-51 TB/s), HBM3E 8 TB/s.
-LDS_PEAK_GBS = 150000.0
+# Peaks from the MI355X micro-architecture guide: HBM3E 8 TB/s; vector ALU 256 CUs x 4 SIMD x 32 lanes
+# x 2.4 GHz = 78.6 T lane-operations/s; LDS aggregate with every CU streaming ds_read_b64/b128 ~150 TB/s.
 HBM_PEAK_GBS = 8000.0
+VALU_PEAK_TLOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+LDS_PEAK_GBS = 150000.0
+
+
+def measured_traffic(kernel_name, frames):
+    """HBM bytes per launch from the rocprofv3 PMC passes recorded in profiles/traffic.json
+    ({kernel prefix: bytes per frame}, = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 / frames, with the
+    gfx950 FETCH_SIZE correction), or None when no measurement is on file for this kernel."""
+    try:
+        tab = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except (OSError, ValueError):
+        return None
+    for k, v in tab.items():
+        if kernel_name.startswith(k):
+            return v * frames
+    return None
 
 
 def lds_bytes_algorithmic(N):
@@ -36,39 +51,24 @@ def lds_bytes_algorithmic(N):
     return 14.5 * N * np.log2(N)
 
 
-def executed_lds_bytes(sched, N, elem=4):
-    """LDS bytes the kernel really moves per frame for a given schedule (fast schedules skip work)."""
-    tot = 0.0
-    n = int(np.log2(N))
-    for w in sched:
-        t, lev = int(w) & 15, (int(w) >> 4) & 31
-        if t in (0, 1):  # F / G: read 2 (from LDS unless top level), write 1
-            h = 1 << (lev - 1)
-            tot += h * elem * (1 if lev == n else 3)
-            if t == 1 and lev - 1 >= 5:
-                tot += h / 8
-        elif t == 5:  # R1: read w values, write w/8 bytes
-            tot += (0 if lev == n else (1 << lev) * elem) + (1 << lev) / 8
-        elif t == 6 and lev - 1 >= 5:  # combine on word arrays
-            tot += 4 * (1 << (lev - 1)) / 8
-        elif t in (2, 3):
-            tot += elem
-    return tot
-
-
-def cpu_baseline(mask, llr_sample, threads):
-    """The CPU oracle's SC decoder (a C restatement of the reference) on the host cores."""
+def cpu_baseline(mask, llr_sample, threads, min_seconds=10.0):
+    """The CPU oracle's SC decoder (a C restatement of the reference) on the host cores: whole passes
+    over the sample, one slice per thread, until at least `min_seconds` have elapsed."""
     from concurrent.futures import ThreadPoolExecutor
 
     from oracle import oracle
 
     oracle.lib()
     parts = np.array_split(llr_sample, threads)
-    t0 = time.perf_counter()
+    done, t0 = 0, time.perf_counter()
     with ThreadPoolExecutor(threads) as ex:
-        list(ex.map(lambda a: oracle.sc_decode_batch(a, mask), parts))
-    dt = time.perf_counter() - t0
-    return llr_sample.shape[0] / dt, dt
+        while True:
+            list(ex.map(lambda a: oracle.sc_decode_batch(a, mask), parts))
+            done += llr_sample.shape[0]
+            dt = time.perf_counter() - t0
+            if dt >= min_seconds:
+                break
+    return done / dt, dt, done
 
 
 def main():
@@ -164,8 +164,6 @@ def main():
         fps = frames_total / dt
         alg_lds = lds_bytes_algorithmic(N) * B
         alg_hbm = (4 * N + K / 8) * B
-        sched_fast = _native.schedule_build(mask, True)
-        sched_plain = _native.schedule_build(mask, False)
         out = {
             "metric": "decoded info Mb/s, Polar(1024,512) SC, Eb/N0=2dB",
             "value": fps * K / 1e6,
@@ -188,29 +186,35 @@ def main():
             "counters": cnt,
             "input_gen_s": gen_s,
             "roofline": {
-                "bound": "lds",
-                "achieved": alg_lds / (k_ms * 1e-3) / 1e9,
-                "peak": LDS_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": alg_lds / (k_ms * 1e-3) / 1e9 / LDS_PEAK_GBS,
-                "traffic": None,
-                "kernel": launch["kernel"],
-                "kernel_ms": k_ms,
-                "algorithmic_bytes_per_frame": lds_bytes_algorithmic(N),
-                "executed_lds_bytes_per_frame": executed_lds_bytes(sched_fast, N),
-                "plain_schedule_lds_bytes_per_frame": executed_lds_bytes(sched_plain, N),
-                "lanes_per_frame": launch["lanes_per_frame"],
-                "grid_blocks": launch["grid_blocks"],
-                "lds_bytes_per_block": launch["lds_bytes_per_block"],
-            },
-            "roofline_hbm": {
                 "bound": "hbm",
                 "achieved": alg_hbm / (k_ms * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": alg_hbm / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": measured_traffic(launch["kernel"], B),
+                "kernel": launch["kernel"],
+                "kernel_ms": k_ms,
                 "algorithmic_bytes_per_frame": 4 * N + K / 8,
+                "lanes_per_frame": launch["lanes_per_frame"],
+                "grid_blocks": launch["grid_blocks"],
+                "lds_bytes_per_block": launch["lds_bytes_per_block"],
+            },
+            "roofline_valu": {
+                "bound": "valu",
+                "achieved": 3.5 * N * np.log2(N) * B / (k_ms * 1e-3) / 1e12,
+                "peak": VALU_PEAK_TLOPS,
+                "unit": "Tlane-op/s",
+                "frac": 3.5 * N * np.log2(N) * B / (k_ms * 1e-3) / 1e12 / VALU_PEAK_TLOPS,
+                "algorithmic_lane_ops_per_frame": 3.5 * N * np.log2(N),
+            },
+            "roofline_lds": {
+                "bound": "lds",
+                "achieved": alg_lds / (k_ms * 1e-3) / 1e9,
+                "peak": LDS_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": alg_lds / (k_ms * 1e-3) / 1e9 / LDS_PEAK_GBS,
+                "algorithmic_bytes_per_frame": lds_bytes_algorithmic(N),
+                "note": "on-chip traffic plain SC would move through LDS; the register-resident kernel keeps it in VGPRs",
             },
         }
 
@@ -238,6 +242,45 @@ def main():
         except _native.PolarError as e:
             extras["scl8"] = {"error": str(e)}
         ctx.enable_timing(False)
+        # SCL L=8 CPU oracle on a bounded sample, for the ratio
+        if not a.no_cpu:
+            from oracle import oracle
+            smp = llr[:64].cpu().numpy()
+            t0 = time.perf_counter()
+            for b_ in range(smp.shape[0]):
+                oracle.scl_decode(smp[b_], mask, 8)
+            extras["scl8"]["cpu_oracle_frames_per_s_1core"] = smp.shape[0] / (time.perf_counter() - t0)
+            extras["scl8"]["reference_python_1core_frames_per_s"] = 3.05
+        # the other configurations of the brief, timed on smaller batches: rate-profiled N=512 with L=32,
+        # and the long code whose LLR tree does not fit a wavefront's registers (LDS-staged kernel)
+        ctx.enable_timing(True)
+        try:
+            m512 = pcf.rmPolarBuild(512, 256, 2.0)
+            c512 = _native.Code(ctx, m512)
+            nb = 1 << 15
+            l512 = torch.empty((nb, 512), dtype=torch.float32, device=dev)
+            c512.gen_frames_dev(None, l512.data_ptr(), np.float32, ch.noisePower, seed, 0, nb)
+            h512 = torch.empty((nb, c512.Kw), dtype=torch.int32, device=dev)
+            c512.scl_decode_dev(l512.data_ptr(), np.float32, 32, h512.data_ptr(), nb)
+            li = c512.last_launch()
+            extras["scl32_rmpolar_512_256"] = {"frames_per_s": nb / (li["last_ms"] * 1e-3), "kernel": li["kernel"], "kernel_ms": li["last_ms"],
+                                               "frames": nb, "lds_bytes_per_block": li["lds_bytes_per_block"]}
+            del l512, h512
+            m16k = pcf.degaBuild(16384, 8192, 2.0)
+            c16k = _native.Code(ctx, m16k)
+            nb = 1 << 15
+            l16k = torch.empty((nb, 16384), dtype=torch.float32, device=dev)
+            c16k.gen_frames_dev(None, l16k.data_ptr(), np.float32, ch.noisePower, seed, 0, nb)
+            h16k = torch.empty((nb, c16k.Kw), dtype=torch.int32, device=dev)
+            c16k.sc_decode_dev(l16k.data_ptr(), np.float32, h16k.data_ptr(), nb, fast=True)
+            li = c16k.last_launch()
+            extras["sc_16384_8192"] = {"frames_per_s": nb / (li["last_ms"] * 1e-3), "info_mbps": nb * 8192 / (li["last_ms"] * 1e-3) / 1e6,
+                                       "kernel": li["kernel"], "kernel_ms": li["last_ms"], "frames": nb,
+                                       "lds_bytes_per_block": li["lds_bytes_per_block"]}
+            del l16k, h16k
+        except _native.PolarError as e:
+            extras["other_configs_error"] = str(e)
+        ctx.enable_timing(False)
         # fused Monte-Carlo pipeline (generate + decode + count), nothing resident beforehand
         t0 = time.perf_counter()
         mc = code.mc_run(_native.DEC_SC, 1, np.float32, ch.noisePower, seed, 0, 1 << 22)
@@ -247,10 +290,11 @@ def main():
 
     if rank == 0 and world == 1 and not a.no_cpu:
         threads = min(16, os.cpu_count() or 1)
-        sample = llr[: 4096 * threads].cpu().numpy()
-        fps_cpu, secs = cpu_baseline(mask, sample, threads)
+        sample = llr[: 8192 * threads].cpu().numpy()
+        fps_cpu, secs, done = cpu_baseline(mask, sample, threads)
         out["cpu_baseline"] = {"value": fps_cpu * K / 1e6, "unit": "Mb/s", "cores": threads, "kind": "port",
-                               "sample": f"{sample.shape[0]} frames of the same LLR batch, oracle SC (C restatement of scDecoder), {secs:.1f} s",
+                               "sample": f"{done} frame decodes ({sample.shape[0]} frames of the same LLR batch, repeated) by the oracle SC decoder "
+                                         f"(C restatement of scDecoder, fp32), {secs:.1f} s on {threads} threads",
                                "frames_per_s": fps_cpu,
                                "reference_python_1core_frames_per_s": 26.4}
 
