@@ -1,6 +1,8 @@
 // Bit packing, the u.F^{(x)n} butterfly encoder, the BPSK/AWGN channel with Philox noise, the fused
 // frame generator and the error counter.  All integer/bit work is one 32-bit word per lane; the
 // cross-word butterfly stages go through LDS.
+#include <algorithm>
+
 #include "philox.h"
 #include "polar_internal.h"
 
@@ -261,6 +263,34 @@ int launch_gen_frames(polar_code *c, uint32_t *info, void *llr, int dtype, doubl
 }
 
 // ------------------------------------------------------------------------------------------ error counter
+// One lane per 32-bit word (coalesced); the words of a frame sit in Kw consecutive lanes (Kw a power of two
+// <= 64), so a frame's bit errors are a segmented butterfly sum over those lanes.
+__global__ void __launch_bounds__(BLOCK) count_errors_words_kernel(const uint32_t *__restrict__ info, const uint32_t *__restrict__ hat,
+                                                                  int64_t total_words, int Kw, unsigned long long *__restrict__ counters)
+{
+    unsigned int be = 0, fe = 0, fr = 0;
+    for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t - (threadIdx.x & 63) < total_words; t += (int64_t)gridDim.x * BLOCK) {
+        unsigned int e = t < total_words ? __popc(info[t] ^ hat[t]) : 0u;
+        for (int off = 1; off < Kw; off <<= 1) e += __shfl_xor(e, off);
+        if ((t & (Kw - 1)) == 0 && t < total_words) {
+            be += e;
+            fe += e > 0 ? 1u : 0u;
+            fr += 1u;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        be += __shfl_down(be, off);
+        fe += __shfl_down(fe, off);
+        fr += __shfl_down(fr, off);
+    }
+    if ((threadIdx.x & 63) == 0 && fr) {
+        atomicAdd(&counters[0], (unsigned long long)fr);
+        if (fe) atomicAdd(&counters[1], (unsigned long long)fe);
+        if (be) atomicAdd(&counters[2], (unsigned long long)be);
+    }
+}
+
+// General case: one frame per lane.
 __global__ void __launch_bounds__(BLOCK) count_errors_kernel(const uint32_t *__restrict__ info, const uint32_t *__restrict__ hat,
                                                             int64_t B, int Kw, unsigned long long *__restrict__ counters)
 {
@@ -284,8 +314,16 @@ __global__ void __launch_bounds__(BLOCK) count_errors_kernel(const uint32_t *__r
 int launch_count_errors(polar_code *c, const uint32_t *info, const uint32_t *hat, int64_t B, uint64_t *counters)
 {
     if (B == 0) return POLAR_OK;
-    hipLaunchKernelGGL(count_errors_kernel, dim3((unsigned)((B + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->ctx->stream, info, hat, B,
-                       c->Kw, (unsigned long long *)counters);
+    const int Kw = c->Kw;
+    if (Kw <= 64 && (Kw & (Kw - 1)) == 0) {
+        int64_t total = B * Kw;
+        int64_t blocks = std::min<int64_t>((total + BLOCK - 1) / BLOCK, (int64_t)c->ctx->num_cus * 16);
+        hipLaunchKernelGGL(count_errors_words_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, c->ctx->stream, info, hat, total, Kw,
+                           (unsigned long long *)counters);
+    } else {
+        hipLaunchKernelGGL(count_errors_kernel, dim3((unsigned)((B + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->ctx->stream, info, hat, B,
+                           Kw, (unsigned long long *)counters);
+    }
     HIP_TRY(hipGetLastError());
     return POLAR_OK;
 }

@@ -257,6 +257,9 @@ __global__ void __launch_bounds__(64, 4) sc_reg_kernel(const T *__restrict__ llr
         if (info_hat) {
             uint32_t *dst = info_hat + fc * Kw;
             const uint32_t *mine = stage + grp * 32;
+            // lane `sub` keeps output words sub and sub + 16; the frame's words then leave as one
+            // contiguous 64-byte store per 16 words instead of sixteen scattered 4-byte stores
+            uint32_t w_lo = 0, w_hi = 0;
             pack_bits_group<16>(
                 K, sub, grp,
                 [&](int k) {
@@ -264,8 +267,15 @@ __global__ void __launch_bounds__(64, 4) sc_reg_kernel(const T *__restrict__ llr
                     return ((mine[(a >> 6) * 2 + ((a >> 5) & 1u)] >> (a & 31u)) & 1u) != 0u;
                 },
                 [&](int wi, uint32_t v) {
-                    if (sub == 0 && active) dst[wi] = v;
+                    if ((wi & 15) == sub) {
+                        if (wi < 16) w_lo = v;
+                        else w_hi = v;
+                    }
                 });
+            if (active) {
+                if (sub < Kw) dst[sub] = w_lo;
+                if (sub + 16 < Kw) dst[sub + 16] = w_hi;
+            }
             if (K == 0 && sub == 0 && active) dst[0] = 0u;
         }
         wave_sync();
