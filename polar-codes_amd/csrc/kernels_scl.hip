@@ -76,11 +76,13 @@ __device__ __forceinline__ float branch_metric(float v, int u)
     float Li = v / 0.69314718055994530942f;
     float e = u ? Li : -Li;
     float m = fmaxf(e, 0.0f);
-    float r = 1.0f - (m + log2f(1.0f + exp2f(-fabsf(e))));
+    // hardware exp2 / log2 (about 1 ulp): this mode only has to match the reference statistically
+    float r = 1.0f - (m + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(e))));
     return e >= 1024.0f ? -INFINITY : r;
 }
 
-template <typename T, int L> __global__ void __launch_bounds__(64) scl_decode_kernel(SCLParams<T> p)
+template <typename T, int L>
+__global__ void __launch_bounds__(64) scl_decode_kernel(SCLParams<T> p, const uint32_t *__restrict__ ops)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int G = 64 / L;
@@ -102,10 +104,12 @@ template <typename T, int L> __global__ void __launch_bounds__(64) scl_decode_ke
         T pm = (T)0;
         int Lcur = 1;
 
+        uint32_t next_op = ops[0];
         for (int pc = 0;; pc++) {
-            const uint32_t op = p.ops[pc];
+            const uint32_t op = next_op;
             const uint32_t type = OP_TYPE(op);
             if (type == OP_END) break;
+            next_op = ops[pc + 1];  // fetched while this operation runs
             const int lev = (int)OP_LEVEL(op);
             const int plane = (int)OP_PLANE(op);
             const bool act = grp < Lcur;
@@ -322,7 +326,7 @@ static int launch_scl_t(polar_code *c, const void *llr, uint32_t *info_hat, doub
     if (occ < 1) occ = 1;
     int64_t grid = std::min<int64_t>(B, (int64_t)ctx->num_cus * occ * 4);
     LaunchTimer tm(ctx);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, ctx->stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, ctx->stream, p, (const uint32_t *)c->d_sched[0]);
     HIP_TRY(hipGetLastError());
     float ms = tm.stop();
     snprintf(c->last.kernel, sizeof(c->last.kernel), "scl_decode_kernel<%s,%d>", sizeof(T) == 4 ? "float" : "double", L);
@@ -356,6 +360,7 @@ int launch_scl_decode(polar_code *c, const void *llr, int dtype, int L, uint32_t
         polar_set_error("SCL decoder: N=%d exceeds the supported maximum of 4096", c->N);
         return POLAR_EUNSUPPORTED;
     }
+    if (scl_reg_supported(c, dtype, L, pm, u_hat_all)) return launch_scl_reg(c, llr, info_hat, B);
     if (dtype == POLAR_F32) return launch_scl_l<float>(c, llr, L, info_hat, pm, u_hat_all, B);
     return launch_scl_l<double>(c, llr, L, info_hat, pm, u_hat_all, B);
 }

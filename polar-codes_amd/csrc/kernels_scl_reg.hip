@@ -1,0 +1,421 @@
+// Register-resident list decoder, L = 8 paths, N = 64 .. 1024, fp32: one wavefront per frame, eight lanes
+// per path.
+//
+// Lane 8p + q belongs to list position p.  Inside a path, element k of every tree level lives in the lane
+// whose element index e(q) equals k mod 8 (e = q for q < 4, 11 - q otherwise, so that the three bottom
+// exchanges are the DPP patterns row_half_mirror, quad_perm[2,3,0,1], quad_perm[1,0,3,2]).  Levels of
+// width >= 16 are per-lane register arithmetic on a slice of N/8 values; partial sums are bit slices.
+//
+// Forking never copies a slice.  Every path keeps, in two 32-bit registers, the list position ("owner")
+// whose registers hold each of its LLR levels and each of its left-child partial-sum levels.  All paths
+// rewrite a level in lockstep, each into its own registers, so an owner's registers stay valid until
+// every path has replaced that level.  Right-child g operations and combines fetch their operands from
+// the owner's lanes with ds_bpermute; a fork or prune only moves the small per-path state (metric, owner
+// rows, the six live values and three live bits of the 8-leaf subtree being decoded).
+//
+// Path metric and ordering follow the reference's sclDecoder / polarSCLFork: PM += 1 - log2(1 + 2^(-+Li));
+// below saturation list = originals ++ copies; at saturation the 16 candidates, ordered copies(u=1) ++
+// originals(u=0), are ranked by (metric descending, candidate position ascending) and rank r < 8 becomes
+// position r.  The metric uses the overflow-free fp32 form with hardware exp2/log2: this kernel is the
+// throughput mode (statistical parity); fp64 parity runs on the LDS-staged kernel.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "polar_internal.h"
+#include "reg_common.h"
+
+__device__ __forceinline__ float bperm_f(float v, int src_lane)
+{
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+}
+__device__ __forceinline__ uint32_t bperm_u(uint32_t v, int src_lane)
+{
+    return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
+}
+__device__ __forceinline__ uint64_t bperm_u64(uint64_t v, int src_lane)
+{
+    return ((uint64_t)bperm_u((uint32_t)(v >> 32), src_lane) << 32) | bperm_u((uint32_t)v, src_lane);
+}
+
+// partner exchange inside an 8-lane path for a period-P replicated vector
+template <int P> __device__ __forceinline__ float partner8(float v)
+{
+    if constexpr (P == 8) return dpp_mov<0x141>(v);       // row_half_mirror: lane i <-> 7 - i of each 8
+    else if constexpr (P == 4) return dpp_mov<0x4E>(v);   // quad_perm:[2,3,0,1]
+    else return dpp_mov<0xB1>(v);                         // quad_perm:[1,0,3,2]
+}
+template <int P> __device__ __forceinline__ uint32_t partner8_u(uint32_t v)
+{
+    if constexpr (P == 8) return dpp_mov_u32<0x141>(v);
+    else if constexpr (P == 4) return dpp_mov_u32<0x4E>(v);
+    else return dpp_mov_u32<0xB1>(v);
+}
+
+// fp32 branch metric of deciding u at decision LLR v (overflow-free; -inf only where the reference overflows)
+__device__ __forceinline__ float branch_metric_fast(float v, uint32_t u)
+{
+    float Li = v / 0.69314718055994530942f;
+    float e = u ? Li : -Li;
+    float m = fmaxf(e, 0.0f);
+    float r = 1.0f - (m + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(e))));
+    return e >= 1024.0f ? -INFINITY : r;
+}
+
+// Small per-path state that moves between lane groups at a fork.
+struct PathState {
+    float pm;
+    uint32_t ownL;   // 3 bits per level l (index l - 3): position whose registers hold my level-l LLRs
+    uint32_t ownP;   // same for the left-child partial sums of level l
+    float lo[3], hi[3];  // operands of the pending g of the enclosing 8-, 4- and 2-leaf nodes
+    uint32_t xb;     // bit I: partial-sum bit of the finished left child of the enclosing node I
+};
+
+struct LaneConst {
+    int lane, p, q, e;
+    bool up[3];          // P = 8, 4, 2: my element is in the upper half
+    uint32_t lowmask[3];
+};
+
+template <int NLOG> struct SclReg {
+    static constexpr int S = 1 << (NLOG - 3);
+    float R[S];           // level l (3 <= l < NLOG): 2^(l-3) values at offset 2^(l-3)
+    uint64_t a0, a1;      // plane 0 partial sums: levels with <= 32 bits per lane in a0 (offset = bit count), 64-bit level in a1
+    uint64_t b0, b1;      // plane 1
+    uint64_t r0, r1;      // root (S bits)
+    PathState st;
+    int Lcur;
+
+    template <int C> static __device__ __forceinline__ uint64_t get_bits(uint64_t w0, uint64_t w1)
+    {
+        if constexpr (C == 64) return w1;
+        else return (w0 >> C) & (((uint64_t)1 << C) - 1);
+    }
+    template <int C> static __device__ __forceinline__ void set_bits(uint64_t &w0, uint64_t &w1, uint64_t x)
+    {
+        if constexpr (C == 64) {
+            w1 = x;
+        } else {
+            const uint64_t m = (((uint64_t)1 << C) - 1) << C;
+            w0 = (w0 & ~m) | (x << C);
+        }
+    }
+    static __device__ __forceinline__ uint32_t own_get(uint32_t row, int lev) { return (row >> (3 * (lev - 3))) & 7u; }
+    static __device__ __forceinline__ uint32_t own_set(uint32_t row, int lev, uint32_t p)
+    {
+        return (row & ~(7u << (3 * (lev - 3)))) | (p << (3 * (lev - 3)));
+    }
+
+    // f: level LEV -> LEV-1 from my own registers (or the channel at the top)
+    template <int LEV> __device__ __forceinline__ void step_f(const float *chan_lane, const LaneConst &lc)
+    {
+        constexpr int c = 1 << (LEV - 4);
+#pragma unroll
+        for (int j = 0; j < c; j++) {
+            float a, b;
+            if constexpr (LEV == NLOG) {
+                a = chan_lane[8 * j];
+                b = chan_lane[8 * (j + c)];
+            } else {
+                a = R[2 * c + j];
+                b = R[3 * c + j];
+            }
+            R[c + j] = f_fast(a, b);
+        }
+        st.ownL = own_set(st.ownL, LEV - 1, (uint32_t)lc.p);
+    }
+    // g: operands and the left child's partial sums come from their owners' lanes
+    template <int LEV> __device__ __forceinline__ void step_g(const float *chan_lane, const LaneConst &lc)
+    {
+        constexpr int c = 1 << (LEV - 4);
+        const int srcP = (int)own_get(st.ownP, LEV - 1) * 8 + lc.q;
+        uint64_t bits;
+        if constexpr (c == 64) bits = bperm_u64(a1, srcP);
+        else if constexpr (c >= 16) bits = (bperm_u64(a0, srcP) >> c) & (((uint64_t)1 << c) - 1);
+        else bits = (uint64_t)((bperm_u((uint32_t)a0, srcP) >> c) & ((1u << c) - 1u));
+        const int srcL = (LEV == NLOG) ? 0 : (int)own_get(st.ownL, LEV) * 8 + lc.q;
+        // operands live at offsets 2c..4c-1, results go to c..2c-1: no lane overwrites what another still reads
+#pragma unroll
+        for (int j = 0; j < c; j++) {
+            float a, b;
+            if constexpr (LEV == NLOG) {
+                a = chan_lane[8 * j];
+                b = chan_lane[8 * (j + c)];
+            } else {
+                a = bperm_f(R[2 * c + j], srcL);
+                b = bperm_f(R[3 * c + j], srcL);
+            }
+            R[c + j] = g_fast(a, b, (uint32_t)(bits >> j) & 1u);
+        }
+        st.ownL = own_set(st.ownL, LEV - 1, (uint32_t)lc.p);
+    }
+    template <int LEV> __device__ __forceinline__ void combine(int plane, const LaneConst &lc)
+    {
+        constexpr int c = 1 << (LEV - 4);  // bits per lane of each child
+        const int srcP = (int)own_get(st.ownP, LEV - 1) * 8 + lc.q;
+        uint64_t xl;
+        if constexpr (c == 64) xl = bperm_u64(a1, srcP);
+        else if constexpr (c >= 16) xl = (bperm_u64(a0, srcP) >> c) & (((uint64_t)1 << c) - 1);
+        else xl = (uint64_t)((bperm_u((uint32_t)a0, srcP) >> c) & ((1u << c) - 1u));
+        const uint64_t xr = get_bits<c>(b0, b1);
+        if constexpr (LEV == NLOG) {
+            if constexpr (c == 64) {
+                r0 = xl ^ xr;
+                r1 = xr;
+            } else {
+                r0 = (xl ^ xr) | (xr << c);
+                r1 = 0;
+            }
+        } else {
+            const uint64_t x = (c == 64) ? 0 : ((xl ^ xr) | (xr << c));
+            if (plane) {
+                set_bits<2 * c>(b0, b1, x);
+            } else {
+                set_bits<2 * c>(a0, a1, x);
+                st.ownP = own_set(st.ownP, LEV, (uint32_t)lc.p);
+            }
+        }
+    }
+
+    // ---- fork / prune: position lc.p becomes (parent position `par`, bit b) ------------------------------
+    __device__ __forceinline__ void take_over(float cpm, int par, uint32_t b, const LaneConst &lc)
+    {
+        const int src = par * 8 + lc.q;
+        st.pm = bperm_f(cpm, par * 8 + 4 * (int)b + (lc.q & 3));  // lanes q >= 4 hold the u=1 candidate metric
+        st.ownL = bperm_u(st.ownL, src);
+        st.ownP = bperm_u(st.ownP, src);
+        st.xb = bperm_u(st.xb, src);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            st.lo[i] = bperm_f(st.lo[i], src);
+            st.hi[i] = bperm_f(st.hi[i], src);
+        }
+    }
+
+    // One leaf.  v is the decision LLR, replicated over the 8 lanes of each path.  Returns the decided bit of
+    // the path that occupies this list position afterwards.
+    __device__ __forceinline__ uint32_t leaf(float v, uint32_t is_info, const LaneConst &lc, uint32_t *surv)
+    {
+        if (!is_info) {
+            st.pm += branch_metric_fast(v, 0u);
+            return 0u;
+        }
+        const uint32_t bme = (uint32_t)lc.q >> 2;  // lanes 0..3 evaluate u = 0, lanes 4..7 evaluate u = 1
+        const float cpm = st.pm + branch_metric_fast(v, bme);
+        int par;
+        uint32_t b;
+        if (2 * Lcur <= 8) {
+            const bool is_copy = lc.p >= Lcur && lc.p < 2 * Lcur;
+            par = is_copy ? lc.p - Lcur : lc.p;
+            b = is_copy ? 1u : 0u;
+            Lcur *= 2;
+        } else {
+            // 16 candidates (p, u); my candidate is (lc.p, bme); my quad lane k compares it with 4 of the 16
+            const int cpos = bme ? lc.p : 8 + lc.p;  // copies (u=1) come first in the candidate order
+            const int k = lc.q & 3;
+            int cnt = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int op = 2 * k + (i >> 1), ob = i & 1;
+                const float opm = bperm_f(cpm, op * 8 + 4 * ob);
+                const int opos = ob ? op : 8 + op;
+                cnt += (opm > cpm || (opm == cpm && opos < cpos)) ? 1 : 0;
+            }
+            cnt += (int)dpp_mov_u32<0xB1>((uint32_t)cnt);
+            cnt += (int)dpp_mov_u32<0x4E>((uint32_t)cnt);
+            if (k == 0 && cnt < 8) surv[cnt] = (uint32_t)(lc.p * 8 + 4 * (int)bme);
+            wave_sync();
+            const uint32_t s = surv[lc.p];
+            wave_sync();
+            par = (int)(s >> 3);
+            b = (s >> 2) & 1u;
+        }
+        take_over(cpm, par, b, lc);
+        return b;
+    }
+
+    // A node of P leaves inside the 8-leaf subtree; v replicated with period P over the path's lanes.
+    template <int P> __device__ __forceinline__ uint32_t sub(float v, uint32_t mask, const LaneConst &lc, uint32_t *surv)
+    {
+        if constexpr (P == 1) {
+            return leaf(v, mask & 1u, lc, surv);
+        } else {
+            constexpr int I = P == 8 ? 0 : P == 4 ? 1 : 2;
+            constexpr uint32_t HALF = (1u << (P / 2)) - 1u;
+            const float o = partner8<P>(v);
+            st.lo[I] = lc.up[I] ? o : v;
+            st.hi[I] = lc.up[I] ? v : o;
+            const float vl = f_fast(v, o);
+            const uint32_t xl = sub<P / 2>(vl, mask & HALF, lc, surv);
+            st.xb = (st.xb & ~(1u << I)) | (xl << I);
+            const float vr = g_fast(st.lo[I], st.hi[I], xl);
+            const uint32_t xr = sub<P / 2>(vr, (mask >> (P / 2)) & HALF, lc, surv);
+            const uint32_t xl_now = (st.xb >> I) & 1u;  // the left result of whoever sits here now
+            return xr ^ (xl_now & lc.lowmask[I]);
+        }
+    }
+};
+
+template <int LEV, int NLOG>
+__device__ __forceinline__ void scl_node(SclReg<NLOG> &d, uint32_t maskv, const float *chan_lane, uint32_t idx, int plane,
+                                         const LaneConst &lc, uint32_t *surv)
+{
+#pragma nounroll
+    for (uint32_t h = 0; h < 2; h++) {
+        if (h == 0) d.template step_f<LEV>(chan_lane, lc);
+        else d.template step_g<LEV>(chan_lane, lc);
+        const uint32_t cidx = 2 * idx + h;
+        if constexpr (LEV - 1 == 3) {
+            const uint32_t mw = (uint32_t)__builtin_amdgcn_readlane((int)maskv, (int)(cidx >> 2));
+            const uint32_t m8 = (mw >> (8 * (cidx & 3))) & 0xFFu;
+            const uint32_t x = d.template sub<8>(d.R[1], m8, lc, surv);
+            if (h) {
+                d.b0 = (d.b0 & ~(uint64_t)2) | ((uint64_t)x << 1);
+            } else {
+                d.a0 = (d.a0 & ~(uint64_t)2) | ((uint64_t)x << 1);
+                d.st.ownP = SclReg<NLOG>::own_set(d.st.ownP, 3, (uint32_t)lc.p);
+            }
+        } else {
+            scl_node<LEV - 1, NLOG>(d, maskv, chan_lane, cidx, (int)h, lc, surv);
+        }
+    }
+    d.template combine<LEV>(plane, lc);
+}
+
+template <int NLOG>
+__global__ void __launch_bounds__(64, 2) scl_reg_kernel(const float *__restrict__ llr, const uint32_t *__restrict__ maskw,
+                                                        const uint32_t *__restrict__ Asl8, uint32_t *__restrict__ info_hat, int64_t B,
+                                                        int K, int Kw)
+{
+    __shared__ uint32_t surv[8];
+    __shared__ uint32_t stage[64 * 4];  // 8 paths x 8 lanes x 128-bit slice of u_hat
+    constexpr int N = 1 << NLOG;
+    LaneConst lc;
+    lc.lane = threadIdx.x;
+    lc.p = lc.lane >> 3;
+    lc.q = lc.lane & 7;
+    lc.e = lc.q < 4 ? lc.q : 11 - lc.q;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        lc.up[i] = (lc.e & (4 >> i)) != 0;
+        lc.lowmask[i] = lc.up[i] ? 0u : 1u;
+    }
+    const uint32_t maskv = maskw[(lc.lane & 31) < (N / 32) ? (lc.lane & 31) : 0];
+    SclReg<NLOG> d;
+
+    for (int64_t f = blockIdx.x; f < B; f += gridDim.x) {
+        const float *chan_lane = llr + f * N + lc.e;
+        d.a0 = d.a1 = d.b0 = d.b1 = d.r0 = d.r1 = 0;
+        d.st.pm = 0.0f;
+        d.st.ownL = d.st.ownP = 0u;
+        d.st.xb = 0u;
+#pragma unroll
+        for (int i = 0; i < 3; i++) d.st.lo[i] = d.st.hi[i] = 0.0f;
+        d.Lcur = 1;
+        scl_node<NLOG, NLOG>(d, maskv, chan_lane, 0u, 0, lc, surv);
+
+        // final stable descending order: rank of every position; the best path is rank 0
+        const bool act = lc.p < d.Lcur;
+        const float spm = act ? d.st.pm : -INFINITY;
+        const int spos = act ? lc.p : 64;
+        int rank = 0;
+        for (int c = 0; c < 8; c++) {
+            const float opm = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(spm), c * 8));
+            const int opos = __builtin_amdgcn_readlane(spos, c * 8);
+            rank += (opm > spm || (opm == spm && opos < spos)) ? 1 : 0;
+        }
+
+        // u_hat = x_hat F^{(x)n} on the sliced layout: element e + 8 j is bit j of my 128-bit root slice
+        uint64_t u0 = d.r0, u1 = d.r1;
+        if constexpr (NLOG > 3) { u0 ^= (u0 >> 1) & 0x5555555555555555ull; u1 ^= (u1 >> 1) & 0x5555555555555555ull; }
+        if constexpr (NLOG > 4) { u0 ^= (u0 >> 2) & 0x3333333333333333ull; u1 ^= (u1 >> 2) & 0x3333333333333333ull; }
+        if constexpr (NLOG > 5) { u0 ^= (u0 >> 4) & 0x0F0F0F0F0F0F0F0Full; u1 ^= (u1 >> 4) & 0x0F0F0F0F0F0F0F0Full; }
+        if constexpr (NLOG > 6) { u0 ^= (u0 >> 8) & 0x00FF00FF00FF00FFull; u1 ^= (u1 >> 8) & 0x00FF00FF00FF00FFull; }
+        if constexpr (NLOG > 7) { u0 ^= (u0 >> 16) & 0x0000FFFF0000FFFFull; u1 ^= (u1 >> 16) & 0x0000FFFF0000FFFFull; }
+        if constexpr (NLOG > 8) { u0 ^= (u0 >> 32) & 0x00000000FFFFFFFFull; u1 ^= (u1 >> 32) & 0x00000000FFFFFFFFull; }
+        if constexpr (NLOG > 9) u0 ^= u1;
+        uint32_t w[4] = {(uint32_t)u0, (uint32_t)(u0 >> 32), (uint32_t)u1, (uint32_t)(u1 >> 32)};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t t;
+            t = partner8_u<2>(w[i]); w[i] ^= (lc.e & 1) ? 0u : t;
+            t = partner8_u<4>(w[i]); w[i] ^= (lc.e & 2) ? 0u : t;
+            t = partner8_u<8>(w[i]); w[i] ^= (lc.e & 4) ? 0u : t;
+            stage[lc.lane * 4 + i] = w[i];
+        }
+        wave_sync();
+        if (info_hat) {
+            uint32_t *dst = info_hat + f * Kw;
+            const uint32_t *mine = stage + lc.p * 32;
+            const bool best = act && rank == 0;
+            uint32_t wout[4] = {0u, 0u, 0u, 0u};
+            pack_bits_group<8>(
+                K, lc.q, lc.p,
+                [&](int k) {
+                    const uint32_t a = Asl8[k];  // (lane-in-path << 7) | bit
+                    return ((mine[(a >> 7) * 4 + ((a >> 5) & 3u)] >> (a & 31u)) & 1u) != 0u;
+                },
+                [&](int wi, uint32_t v) {
+                    if ((wi & 7) == lc.q) {
+                        if (wi < 8) wout[0] = v;
+                        else if (wi < 16) wout[1] = v;
+                        else if (wi < 24) wout[2] = v;
+                        else wout[3] = v;
+                    }
+                });
+            if (best) {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (lc.q + 8 * i < Kw) dst[lc.q + 8 * i] = wout[i];
+            }
+            if (K == 0 && lc.lane == 0) dst[0] = 0u;
+        }
+        wave_sync();
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+bool scl_reg_supported(const polar_code *c, int dtype, int L, const void *pm, const void *u_hat_all)
+{
+    if (dtype != POLAR_F32 || L != 8 || pm || u_hat_all) return false;
+    if (c->n < 6 || c->n > 10 || c->K < 3) return false;
+    const char *e = getenv("POLAR_SCL_KERNEL");
+    if (e && e[0] == 'l') return false;  // "lds": force the LDS-staged kernel
+    return true;
+}
+
+template <int NLOG> static int launch_scl_reg_t(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B)
+{
+    polar_ctx *ctx = c->ctx;
+    auto kern = scl_reg_kernel<NLOG>;
+    int occ = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, 0));
+    if (occ < 1) occ = 1;
+    int64_t grid = std::min<int64_t>(B, (int64_t)ctx->num_cus * occ * 8);
+    LaunchTimer tm(ctx);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), 0, ctx->stream, (const float *)llr, (const uint32_t *)c->d_maskw,
+                       (const uint32_t *)c->d_Asl8, info_hat, B, c->K, c->Kw);
+    HIP_TRY(hipGetLastError());
+    float ms = tm.stop();
+    snprintf(c->last.kernel, sizeof(c->last.kernel), "scl_reg_kernel<%d>/L8", NLOG);
+    c->last.lanes_per_frame = 64;
+    c->last.lds_bytes_per_block = 32 + 1024;
+    c->last.block_threads = 64;
+    c->last.grid_blocks = (int)grid;
+    c->last.last_ms = ms;
+    return POLAR_OK;
+}
+
+int launch_scl_reg(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B)
+{
+    if (B == 0) return POLAR_OK;
+    switch (c->n) {
+    case 6: return launch_scl_reg_t<6>(c, llr, info_hat, B);
+    case 7: return launch_scl_reg_t<7>(c, llr, info_hat, B);
+    case 8: return launch_scl_reg_t<8>(c, llr, info_hat, B);
+    case 9: return launch_scl_reg_t<9>(c, llr, info_hat, B);
+    case 10: return launch_scl_reg_t<10>(c, llr, info_hat, B);
+    default: polar_set_error("register SCL kernel: unsupported length"); return POLAR_EUNSUPPORTED;
+    }
+}

@@ -180,8 +180,14 @@ extern "C" int polar_code_create(polar_ctx *ctx, int N, const uint8_t *mask, pol
     c->sched[1] = build_schedule(c->mask.data(), N, true);
     std::vector<uint32_t> Asl;
     for (uint32_t pos : A) Asl.push_back(((pos & 15u) << 6) | (pos >> 4));
+    std::vector<uint32_t> Asl8;
+    for (uint32_t pos : A) {
+        uint32_t e = pos & 7u, q = e < 4 ? e : 11 - e;
+        Asl8.push_back((q << 7) | (pos >> 3));
+    }
     if (A.empty()) A.push_back(0);
     if (Asl.empty()) Asl.push_back(0);
+    if (Asl8.empty()) Asl8.push_back(0);
 
     auto up = [&](uint32_t **dst, const std::vector<uint32_t> &v) -> int {
         HIP_TRY(hipMalloc((void **)dst, v.size() * sizeof(uint32_t)));
@@ -190,7 +196,7 @@ extern "C" int polar_code_create(polar_ctx *ctx, int N, const uint8_t *mask, pol
     };
     int rc;
     if ((rc = up(&c->d_maskw, maskw)) || (rc = up(&c->d_rank, rank)) || (rc = up(&c->d_A, A)) ||
-        (rc = up(&c->d_sched[0], c->sched[0])) || (rc = up(&c->d_sched[1], c->sched[1])) || (rc = up(&c->d_Asl, Asl))) {
+        (rc = up(&c->d_sched[0], c->sched[0])) || (rc = up(&c->d_sched[1], c->sched[1])) || (rc = up(&c->d_Asl, Asl)) || (rc = up(&c->d_Asl8, Asl8))) {
         polar_code_destroy(c);
         return rc;
     }
@@ -203,7 +209,7 @@ extern "C" int polar_code_destroy(polar_code *c)
     if (!c) return POLAR_OK;
     (void)hipSetDevice(c->ctx->device);
     (void)hipStreamSynchronize(c->ctx->stream);
-    uint32_t *ps[] = {c->d_maskw, c->d_rank, c->d_A, c->d_sched[0], c->d_sched[1], c->d_sched[2], c->d_sched[3], c->d_Asl};
+    uint32_t *ps[] = {c->d_maskw, c->d_rank, c->d_A, c->d_sched[0], c->d_sched[1], c->d_sched[2], c->d_sched[3], c->d_Asl, c->d_Asl8};
     for (uint32_t *p : ps)
         if (p) (void)hipFree(p);
     delete c;

@@ -84,6 +84,7 @@ struct polar_code {
     uint32_t *d_rank = nullptr;    // Nw words: info bits before word w
     uint32_t *d_A = nullptr;       // K info positions, ascending
     uint32_t *d_sched[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t *d_Asl8 = nullptr;    // same for the 8-lanes-per-path layout: (lane-in-path << 7) | bit
     uint32_t *d_Asl = nullptr;     // K entries: (lane << 6) | bit of each info position in the sliced layout
     polar_launch_info last{};
 };
@@ -100,6 +101,8 @@ int launch_sc_decode(polar_code *c, const void *llr, int dtype, uint32_t *info_h
                      void *dec_llr, int64_t B, int flags);
 bool sc_reg_supported(const polar_code *c, int dtype, const void *u_hat, const void *dec_llr);
 int launch_sc_reg(polar_code *c, const void *llr, int dtype, uint32_t *info_hat, int64_t B, int flags);
+bool scl_reg_supported(const polar_code *c, int dtype, int L, const void *pm, const void *u_hat_all);
+int launch_scl_reg(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B);
 int launch_scl_decode(polar_code *c, const void *llr, int dtype, int L, uint32_t *info_hat, double *pm,
                       uint32_t *u_hat_all, int64_t B);
 int launch_count_errors(polar_code *c, const uint32_t *info, const uint32_t *hat, int64_t B, uint64_t *counters);
