@@ -195,7 +195,7 @@ static double branch_metric(double llr, int u)
  * max(e,0) + log2(1 + 2^-|e|) and only reproduces the reference's -inf for e >= 1024. */
 static double branch_metric_f32(float llr, int u)
 {
-    float Li = llr / 0.69314718055994530942f;
+    float Li = llr * 1.44269504088896340736f;
     float e = u ? Li : -Li;
     if (e >= 1024.0f) return -INFINITY;
     float m = e > 0 ? e : 0.0f;

@@ -73,7 +73,7 @@ __device__ __forceinline__ double branch_metric(double v, int u)
 // fp32 mode: overflow-free form; only the reference's -inf for e >= 1024 is reproduced.
 __device__ __forceinline__ float branch_metric(float v, int u)
 {
-    float Li = v / 0.69314718055994530942f;
+    float Li = v * 1.44269504088896340736f;  // 1/ln2 (the fp64 parity path divides by ln2 like the reference)
     float e = u ? Li : -Li;
     float m = fmaxf(e, 0.0f);
     // hardware exp2 / log2 (about 1 ulp): this mode only has to match the reference statistically

@@ -56,7 +56,7 @@ template <int P> __device__ __forceinline__ uint32_t partner8_u(uint32_t v)
 // fp32 branch metric of deciding u at decision LLR v (overflow-free; -inf only where the reference overflows)
 __device__ __forceinline__ float branch_metric_fast(float v, uint32_t u)
 {
-    float Li = v / 0.69314718055994530942f;
+    float Li = v * 1.44269504088896340736f;  // 1/ln2 (the fp64 parity path divides by ln2 like the reference)
     float e = u ? Li : -Li;
     float m = fmaxf(e, 0.0f);
     float r = 1.0f - (m + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(e))));
