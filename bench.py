@@ -90,10 +90,26 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)  # rehearsals with more ranks than GPUs share devices (gloo only)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    backend = os.environ.get("POLAR_BENCH_BACKEND", "nccl")  # "gloo" only to rehearse the multi-rank path on one GPU
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+
+    def all_reduce(t, op=None):
+        """RCCL all-reduce on the device tensor; through a host copy when rehearsing over gloo."""
+        op = op or dist.ReduceOp.SUM
+        if backend == "nccl":
+            dist.all_reduce(t, op=op)
+        else:
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
 
     import _native
     import functions as pcf
@@ -132,7 +148,7 @@ def main():
         code.count_errors_dev(info.data_ptr(), hat.data_ptr(), B, counters.data_ptr())
         ctx.sync()
         if world > 1:
-            dist.all_reduce(counters)
+            all_reduce(counters)
 
     for _ in range(a.warmup):
         step()
@@ -144,7 +160,7 @@ def main():
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        all_reduce(tmax, dist.ReduceOp.MAX)
     dt = float(tmax.item())
     cnt = counters.cpu().tolist()
 
@@ -170,11 +186,11 @@ def main():
         code.count_errors_dev(info.data_ptr(), hat.data_ptr(), nb, c2.data_ptr())
         ctx.sync()
         if world > 1:
-            dist.all_reduce(c2)
+            all_reduce(c2)
         barrier()
         sdt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         if world > 1:
-            dist.all_reduce(sdt, op=dist.ReduceOp.MAX)
+            all_reduce(sdt, dist.ReduceOp.MAX)
         c2 = c2.cpu().tolist()
         scl = {"frames_per_s": nb * world / float(sdt.item()), "info_mbps": nb * world * K / float(sdt.item()) / 1e6,
                "frames_per_gpu": nb, "fer": c2[1] / max(c2[0], 1), "kernel": code.last_launch()["kernel"],

@@ -71,7 +71,12 @@ class PolarCode:
         self.crcWidth = 0
         self.decoderType = "sc"
         self.dtype = np.float64  # arithmetic type of the decoders: float64 = parity with the reference
+        # bitReversed = True reproduces the ordering of the reference's stand-alone script cn/main.py:233,255-273:
+        # the encoder is fed u[indicesRev] and step i of the decoder decides uHat[bitreversed(i)] with
+        # polarMask[bitreversed(i)] -- i.e. the natural-order code with the bit-reversed rate profile.
+        self.bitReversed = False
         self._code = None
+        self._code_rev = None
 
     # ---- lazily built pieces ------------------------------------------------------------------------
     @property
@@ -87,6 +92,19 @@ class PolarCode:
         if self._code is None:
             self._code = _native.Code(_native.default_ctx(), self.polarMask)
         return self._code
+
+    @property
+    def _rev(self):
+        return np.asarray(self.indicesRev)
+
+    @property
+    def _active(self):
+        """Device code object of the ordering in force (natural, or bit-reversed rate profile)."""
+        if not self.bitReversed:
+            return self.native
+        if self._code_rev is None:
+            self._code_rev = _native.Code(_native.default_ctx(), self.polarMask[self._rev])
+        return self._code_rev
 
     # ---- encode -------------------------------------------------------------------------------------
     def rateProfile(self, info):
@@ -109,6 +127,9 @@ class PolarCode:
     def polarEncode(self, info):
         """mul_matrix(rateProfile(info)) in one GPU call (cn/polarCode.py:250-255)."""
         info = np.asarray(info)
+        if self.bitReversed:  # cn/main.py:228-233: x = mul_matrix(u[indicesRev])
+            v = self.rateProfile(info)[..., self._rev]
+            return self.native.mul_matrix(v.reshape(-1, self.codewordLength)).reshape(v.shape).astype(int)
         x = self.native.encode(info.reshape(int(np.prod(info.shape[:-1], dtype=np.int64)), self.infoLen))
         return x.reshape(info.shape[:-1] + (self.codewordLength,)).astype(int)
 
@@ -139,9 +160,12 @@ class PolarCode:
             raise NotImplementedError("bit flipping (sequenceU) is not provided")
         llr = self._llr(softMess)
         batch = llr.shape[:-1]
-        info, uh, dl = self.native.sc_decode(llr.reshape(-1, self.codewordLength), want_uhat=True, want_llrs=True)
+        info, uh, dl = self._active.sc_decode(llr.reshape(-1, self.codewordLength), want_uhat=True, want_llrs=True)
+        if self.bitReversed:  # decoder step i decided uHat[bitreversed(i)] (cn/main.py:256-273)
+            uh = uh[:, self._rev]
+            info = uh[:, self.polarMask == 1]
         self.uHat = uh.reshape(batch + (self.codewordLength,)).astype(int)
-        self.llrs = dl.reshape(batch + (self.codewordLength,))
+        self.llrs = dl.reshape(batch + (self.codewordLength,))  # in decoding-step order, like main.py's llrOb
         self.ANV = self.codewordLength
         self.mT = -6
         self.predictIdx = []
@@ -156,7 +180,10 @@ class PolarCode:
         L = int(self.L)
         llr = self._llr(softMess)
         batch = llr.shape[:-1]
-        info, pm, uh = self.native.scl_decode(llr.reshape(-1, self.codewordLength), L, want_list=True)
+        info, pm, uh = self._active.scl_decode(llr.reshape(-1, self.codewordLength), L, want_list=True)
+        if self.bitReversed:
+            uh = uh[:, :, self._rev]
+            info = uh[:, 0][:, self.polarMask == 1]
         nsurv = min(L, 2 ** self.infoLen) if self.infoLen < 6 else L
         if batch == ():
             self.pathList = [Path(uh[0, j].astype(int), pm[0, j]) for j in range(nsurv)]

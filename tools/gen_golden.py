@@ -325,7 +325,31 @@ def gen_curves(functions, polarCode, channel):
             np.savez_compressed(os.path.join(OUT, "curves.npz"), **out)
 
 
-SECTIONS = {"masks": gen_masks, "encoder": gen_encoder, "channel": gen_channel, "sc": gen_sc, "scl": gen_scl, "curves": gen_curves}
+# --------------------------------------------------------------------------- main.py flow (bit-reversed variant)
+def gen_mainflow(functions, polarCode, channel):
+    """cn/main.py is a script: executing it decodes one random (1024,512) frame at 1 dB in its bit-reversed
+    ordering.  Seed numpy, execute it, and keep the inputs and outputs it leaves in its module globals."""
+    import importlib
+
+    out = {}
+    main = None
+    for s in range(1, 9):
+        np.random.seed(700 + s)
+        with contextlib.redirect_stdout(io.StringIO()):
+            main = importlib.import_module("main") if main is None else importlib.reload(main)
+        out[f"s{s}_message"] = packbits(main.message)
+        out[f"s{s}_x"] = packbits(main.x)
+        out[f"s{s}_llr"] = np.asarray(main.llrCh, dtype=np.float64)
+        out[f"s{s}_uhat"] = packbits(main.uHat)
+        out[f"s{s}_decoded"] = packbits(main.decoded)
+        out[f"s{s}_decllr"] = np.asarray(main.llrOb, dtype=np.float64)
+    out["mask"] = packbits(main.polarMask)
+    out["dsnr"] = np.array([2.5])
+    np.savez_compressed(os.path.join(OUT, "mainflow.npz"), **out)
+    print("mainflow:", len(out), "arrays; last frame correct:", bool((main.message == main.decoded).all()))
+
+
+SECTIONS = {"masks": gen_masks, "encoder": gen_encoder, "channel": gen_channel, "sc": gen_sc, "scl": gen_scl, "curves": gen_curves, "mainflow": gen_mainflow}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
