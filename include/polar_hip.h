@@ -41,10 +41,13 @@ enum {
     POLAR_ENOMEM = -3,   /* device or host allocation failed */
     POLAR_EUNSUPPORTED = -4
 };
-/* flags for polar_sc_decode* */
+/* flags */
 enum {
-    POLAR_SC_FAST = 1    /* skip all-frozen subtrees and hard-decide all-information subtrees
-                            (same decisions as plain SC; decision LLRs are then not available) */
+    POLAR_SC_FAST = 1,   /* polar_sc_decode*, polar_mc_run: skip all-frozen subtrees and hard-decide
+                            all-information subtrees (same decisions as plain SC; decision LLRs are then
+                            not available) */
+    POLAR_CRC = 2        /* polar_gen_frames, polar_scl_decode*, polar_count_errors, polar_mc_run: the last
+                            `width` information bits are the CRC set with polar_code_set_crc */
 };
 
 const char *polar_last_error(void);
@@ -68,6 +71,12 @@ int polar_code_n(const polar_code *code);
 int polar_code_k(const polar_code *code);
 /* Number of decoder schedule operations: which = 0 plain SC (visits every leaf), 1 = fast SC. */
 int polar_code_schedule_len(const polar_code *code, int which);
+/* CRC of CRC-aided list decoding: pcode.crcPoly / pcode.crcWidth (cn/simulator.py:84-85) as consumed by
+ * pcf.crcEncode (cn/functions.py:567-583).  crc_poly holds the generator polynomial with its leading term
+ * (0x107 = x^8+x^2+x+1); the width is its degree, 1..32 and at most K.  0 removes the CRC.  The K information
+ * bits are then K - width message bits followed by the CRC, MSB first. */
+int polar_code_set_crc(polar_code *code, uint64_t crc_poly);
+int polar_code_crc_width(const polar_code *code);
 
 /* Host-only: writes the decoder schedule compiled from `mask` (one 32-bit word per operation, see
  * polar-codes_amd/csrc/polar_internal.h for the encoding) into out[0..cap) and returns its length, or a
@@ -89,9 +98,11 @@ int polar_channel_llr(polar_code *code, const uint8_t *x, void *llr, int dtype, 
 
 /* ---- synthetic Monte-Carlo inputs: the body of the frame loop up to the decoder
  *      (cn/simulator.py:138,148-154): random info bits (Philox stream 0), encode, channel.
- *      Device buffers only.  info_packed [B x ceil(K/32)] (may be NULL), llr [B x N]. */
+ *      Device buffers only.  info_packed [B x ceil(K/32)] (may be NULL), llr [B x N].
+ *      With POLAR_CRC only the first K - width bits are random and the CRC is appended before encoding
+ *      (PolarCode.CRCPolarEncode2, cn/polarCode.py:265-271). */
 int polar_gen_frames(polar_code *code, uint32_t *info_packed, void *llr, int dtype, double N0, uint64_t seed,
-                     uint64_t frame0, int64_t B);
+                     uint64_t frame0, int64_t B, int flags);
 
 /* ---- SC decoder: PolarCode.scDecoder (cn/polarCode.py:1525-1571) with Path.updateLLRs /
  *      updateBits (cn/polarCode.py:30-85) for a batch.  llr [B x N];
@@ -106,22 +117,26 @@ int polar_sc_decode_packed(polar_code *code, const void *llr, int dtype, uint32_
  *      info_hat [B x K] from the best path; pm_sorted [B x L] doubles, final path metrics in the
  *      reference's final order (stable, descending) or NULL; u_hat_all [B x L x N] or NULL
  *      (the whole sorted list, self.pathList[j].uHat).  Lists shorter than L (fewer than log2 L
- *      information bits) are padded with -inf metrics and zero bits. */
+ *      information bits) are padded with -inf metrics and zero bits.
+ *      With POLAR_CRC (sclDecoder(isCRC=True), cn/polarCode.py:2079-2097) info_hat comes from the first
+ *      path of the sorted list whose K information bits leave a zero CRC remainder, the best path if none
+ *      does; it still holds all K bits (the caller drops the last `width`); the list outputs do not change. */
 int polar_scl_decode(polar_code *code, const void *llr, int dtype, int L, uint8_t *info_hat, double *pm_sorted,
-                     uint8_t *u_hat_all, int64_t B, int space);
+                     uint8_t *u_hat_all, int64_t B, int flags, int space);
 int polar_scl_decode_packed(polar_code *code, const void *llr, int dtype, int L, uint32_t *info_hat,
-                            double *pm_sorted, uint32_t *u_hat_all, int64_t B, int space);
+                            double *pm_sorted, uint32_t *u_hat_all, int64_t B, int flags, int space);
 
 /* ---- error counting: pcf.fails per frame (cn/functions.py:107-109) plus the fer/ber counters of the
  *      driver loop (cn/simulator.py:216-226).  Adds to counters[0..2] = frames, frame errors, bit errors
- *      (device uint64[3]).  Packed device buffers. */
+ *      (device uint64[3]).  Packed device buffers.  With POLAR_CRC only the K - width message bits count. */
 int polar_count_errors(polar_code *code, const uint32_t *info_packed, const uint32_t *info_hat_packed, int64_t B,
-                       uint64_t *counters_dev);
+                       int flags, uint64_t *counters_dev);
 
 /* ---- fused Monte-Carlo run: the frame loop of cn/simulator.py:136-156,216-226 for global frame indices
  *      [frame0, frame0 + nframes).  Nothing but the three counters leaves the GPU.
  *      counters (host uint64[3]) are ADDED to. Frame f always sees the same inputs whatever the chunking
- *      or the number of GPUs, because the generator is keyed by the global frame index. */
+ *      or the number of GPUs, because the generator is keyed by the global frame index.
+ *      flags: POLAR_SC_FAST (SC), POLAR_CRC (SCL: CRC-aided frames, selection and counting). */
 int polar_mc_run(polar_code *code, int decoder, int L, int dtype, int flags, double N0, uint64_t seed,
                  uint64_t frame0, int64_t nframes, uint64_t counters[3]);
 

@@ -49,6 +49,10 @@ def lib():
         L.orc_gen_frame.argtypes = [C.c_uint64, C.c_uint64, _u8p, C.c_int, C.c_int, C.c_double, _u8p, _u8p, _f64p]
         L.orc_mc_run.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                  C.c_uint64, C.c_uint64, C.c_int64, _u64p]
+        L.orc_crc_encode.argtypes = [_u8p, C.c_int, C.c_uint64, _u8p]
+        L.orc_ca_select.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_uint64]
+        L.orc_mc_run_crc.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint64,
+                                     C.c_uint64, C.c_uint64, C.c_int64, _u64p]
         _lib = L
     return _lib
 
@@ -151,4 +155,36 @@ def mc_run(mask, decoder, L, dtype, N0, seed, frame0, nframes):
     m = _mask(mask)
     c = np.zeros(3, dtype=np.uint64)
     lib().orc_mc_run(m, m.size, int(m.sum()), decoder, L, dtype, float(N0), seed, frame0, nframes, c)
+    return c
+
+
+def crc_encode(message, crc_poly):
+    """message ++ CRC (crc_poly with its leading term, e.g. 0x107)."""
+    msg = np.ascontiguousarray(message, dtype=np.uint8)
+    w = int(crc_poly).bit_length() - 1
+    out = np.empty(msg.size + w, dtype=np.uint8)
+    lib().orc_crc_encode(msg, msg.size, int(crc_poly), out)
+    return out
+
+
+def ca_select(uhat_sorted, mask, crc_poly):
+    """Row of the sorted list that CRC-aided decoding returns."""
+    m = _mask(mask)
+    uh = np.ascontiguousarray(uhat_sorted, dtype=np.uint8)
+    return lib().orc_ca_select(uh, m, m.size, uh.shape[0], int(crc_poly))
+
+
+def ca_scl_decode(llr, mask, L, crc_poly):
+    """Single frame, CRC-aided: decoded message bits (K - width)."""
+    uh, pm, _ = scl_decode(llr, mask, L)
+    j = ca_select(uh, mask, crc_poly)
+    w = int(crc_poly).bit_length() - 1
+    word = extract(uh[j], mask)
+    return word[:word.size - w]
+
+
+def mc_run_crc(mask, L, dtype, N0, crc_poly, seed, frame0, nframes):
+    m = _mask(mask)
+    c = np.zeros(3, dtype=np.uint64)
+    lib().orc_mc_run_crc(m, m.size, int(m.sum()), L, dtype, float(N0), int(crc_poly), seed, frame0, nframes, c)
     return c

@@ -392,3 +392,93 @@ ORC_API void orc_mc_run(const uint8_t *mask, int N, int K, int decoder, int L, i
     }
     free(info); free(x); free(uh); free(dec); free(llr); free(pm); free(llrf);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * CRC-aided list decoding
+ * ------------------------------------------------------------------------------------------------ */
+
+/* pcf.crcEncode (cn/functions.py:567-583) with the bit-array register of the reference: the polynomial's
+ * coefficients below the leading term (pcf.standardForm, cn/functions.py:83-92), MSB first; message of n bits
+ * followed by w zeros is shifted in; out = message ++ register (n + w bits).  crc_poly carries the leading
+ * term (0x107: w = 8). */
+ORC_API int orc_crc_encode(const uint8_t *message, int n, uint64_t crc_poly, uint8_t *out)
+{
+    int w = 0;
+    while ((crc_poly >> (w + 1)) != 0) w++;
+    uint8_t poly[64], reg[64];
+    for (int j = 0; j < w; j++) {
+        poly[j] = (uint8_t)((crc_poly >> (w - 1 - j)) & 1u);
+        reg[j] = 0;
+    }
+    for (int i = 0; i < n + w; i++) {
+        uint8_t bit = i < n ? message[i] : 0;
+        uint8_t top = reg[0];
+        for (int j = 0; j + 1 < w; j++) reg[j] = reg[j + 1];
+        reg[w - 1] = bit;
+        if (top)
+            for (int j = 0; j < w; j++) reg[j] ^= poly[j];
+    }
+    for (int i = 0; i < n; i++) out[i] = message[i];
+    for (int j = 0; j < w; j++) out[n + j] = reg[j];
+    return w;
+}
+
+/* The choice at the end of sclDecoder(isCRC=True) (cn/polarCode.py:2079-2097): the sorted list is scanned
+ * for the first path whose extracted information word, run through crcEncode once more, leaves an all-zero
+ * tail; without one the best path stays.  uhat_sorted: nsurv rows of N bits.  Returns the chosen row. */
+ORC_API int orc_ca_select(const uint8_t *uhat_sorted, const uint8_t *mask, int N, int nsurv, uint64_t crc_poly)
+{
+    uint8_t *word = malloc((size_t)N), *enc = malloc((size_t)N + 64);
+    int chosen = 0, found = 0;
+    for (int j = 0; j < nsurv && !found; j++) {
+        int K = orc_extract(uhat_sorted + (size_t)j * N, mask, N, word);
+        int w = orc_crc_encode(word, K, crc_poly, enc);
+        int sum = 0;
+        for (int t = 0; t < w; t++) sum += enc[K + t];
+        if (sum == 0) {
+            chosen = j;
+            found = 1;
+        }
+    }
+    free(word);
+    free(enc);
+    return chosen;
+}
+
+/* CRC-aided Monte-Carlo loop: as orc_mc_run with the list decoder, but the first K - w information bits are
+ * the message (the same Philox bits a CRC-less frame would start with), the CRC fills the rest
+ * (CRCPolarEncode2, cn/polarCode.py:265-271), the decoder's choice is CRC-aided and only message bits count. */
+ORC_API void orc_mc_run_crc(const uint8_t *mask, int N, int K, int L, int dtype, double N0, uint64_t crc_poly,
+                            uint64_t seed, uint64_t frame0, int64_t nframes, uint64_t counters[3])
+{
+    int w = 0;
+    while ((crc_poly >> (w + 1)) != 0) w++;
+    const int Km = K - w;
+    uint8_t *info = malloc(K + 64), *msg = malloc(K), *x = malloc(N), *uh = malloc((size_t)N * L), *dec = malloc(K);
+    double *llr = malloc(sizeof(double) * N), *pm = malloc(sizeof(double) * L), *z = malloc(sizeof(double) * N);
+    float *llrf = malloc(sizeof(float) * N);
+    int64_t counts[3];
+    for (int64_t f = 0; f < nframes; f++) {
+        orc_gen_info(seed, frame0 + f, K, msg);
+        orc_crc_encode(msg, Km, crc_poly, info);
+        orc_polar_encode(info, mask, N, x);
+        orc_gen_noise(seed, frame0 + f, N, z);
+        double sigma = sqrt(N0 / 2.0), gain = 4.0 / N0;
+        for (int i = 0; i < N; i++) llr[i] = gain * ((double)(1 - 2 * (int)x[i]) + sigma * z[i]);
+        if (dtype == 0) {
+            for (int i = 0; i < N; i++) llrf[i] = (float)llr[i];
+            orc_scl_decode_f32(llrf, mask, N, L, uh, pm, counts);
+        } else {
+            orc_scl_decode_f64(llr, mask, N, L, uh, pm, counts);
+        }
+        int nsurv = L;
+        if (K < 6 && (1 << K) < L) nsurv = 1 << K;
+        int j = orc_ca_select(uh, mask, N, nsurv, crc_poly);
+        orc_extract(uh + (size_t)j * N, mask, N, dec);
+        int64_t e = orc_fails(info, dec, Km);
+        counters[0] += 1;
+        counters[1] += (e > 0);
+        counters[2] += (uint64_t)e;
+    }
+    free(info); free(msg); free(x); free(uh); free(dec); free(llr); free(pm); free(z); free(llrf);
+}

@@ -14,6 +14,7 @@ HOST, DEVICE = 0, 1
 F32, F64 = 0, 1
 DEC_SC, DEC_SCL = 0, 1
 SC_FAST = 1
+CRC = 2
 
 _lib = None
 _default_ctx = None
@@ -44,17 +45,19 @@ SIGNATURES = {
     "polar_code_n": (_i, [_vp]),
     "polar_code_k": (_i, [_vp]),
     "polar_code_schedule_len": (_i, [_vp, _i]),
+    "polar_code_set_crc": (_i, [_vp, _u64]),
+    "polar_code_crc_width": (_i, [_vp]),
     "polar_schedule_build": (_i, [_vp, _i, _i, _vp, _i]),
     "polar_encode": (_i, [_vp, _vp, _vp, _i64, _i]),
     "polar_encode_packed": (_i, [_vp, _vp, _vp, _i64, _i]),
     "polar_mul_matrix": (_i, [_vp, _vp, _vp, _i64, _i]),
     "polar_channel_llr": (_i, [_vp, _vp, _vp, _i, _d, _u64, _u64, _i64, _i]),
-    "polar_gen_frames": (_i, [_vp, _vp, _vp, _i, _d, _u64, _u64, _i64]),
+    "polar_gen_frames": (_i, [_vp, _vp, _vp, _i, _d, _u64, _u64, _i64, _i]),
     "polar_sc_decode": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _i]),
     "polar_sc_decode_packed": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _i]),
-    "polar_scl_decode": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _i64, _i]),
-    "polar_scl_decode_packed": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _i64, _i]),
-    "polar_count_errors": (_i, [_vp, _vp, _vp, _i64, _vp]),
+    "polar_scl_decode": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _i64, _i, _i]),
+    "polar_scl_decode_packed": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _i64, _i, _i]),
+    "polar_count_errors": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "polar_mc_run": (_i, [_vp, _i, _i, _i, _i, _d, _u64, _u64, _i64, _vp]),
     "polar_last_launch": (_i, [_vp, C.POINTER(LaunchInfo)]),
 }
@@ -66,6 +69,13 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise PolarError("libpolar_hip.so not found at %s: build it first (make -C polar-codes_amd/csrc)" % LIB_PATH)
+        try:
+            # PyTorch ships its own copy of the HIP/HSA runtime.  A process can only work with one: if this
+            # library pulled in the system runtime first, torch.cuda would later find no GPU.  Loading torch
+            # first makes both use the same runtime, in whichever order the caller touches the GPU.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
@@ -135,6 +145,7 @@ class Code:
         self.K = lib().polar_code_k(self._h)
         self.Nw = (self.N + 31) // 32
         self.Kw = max(1, (self.K + 31) // 32)
+        self.crc_width = 0
 
     def close(self):
         if self._h:
@@ -149,6 +160,11 @@ class Code:
 
     def schedule_len(self, fast):
         return lib().polar_code_schedule_len(self._h, 1 if fast else 0)
+
+    def set_crc(self, crc_poly):
+        """Attach (or with 0 remove) the CRC generator polynomial, leading term included (0x107 = CRC-8)."""
+        _check(lib().polar_code_set_crc(self._h, int(crc_poly)))
+        self.crc_width = lib().polar_code_crc_width(self._h)
 
     def last_launch(self):
         li = LaunchInfo()
@@ -193,7 +209,7 @@ class Code:
                                      SC_FAST if fast else 0, HOST))
         return info, uh, dl
 
-    def scl_decode(self, llr, L, want_list=False):
+    def scl_decode(self, llr, L, want_list=False, crc=False):
         llr = np.ascontiguousarray(np.atleast_2d(llr))
         if llr.dtype not in (np.float32, np.float64):
             llr = llr.astype(np.float64)
@@ -202,28 +218,31 @@ class Code:
         info = np.empty((B, self.K), dtype=np.uint8)
         pm = np.empty((B, L), dtype=np.float64) if want_list else None
         uh = np.empty((B, L, self.N), dtype=np.uint8) if want_list else None
-        _check(lib().polar_scl_decode(self._h, llr.ctypes.data, _dt(llr.dtype), L, info.ctypes.data, _ptr(pm), _ptr(uh), B, HOST))
+        _check(lib().polar_scl_decode(self._h, llr.ctypes.data, _dt(llr.dtype), L, info.ctypes.data, _ptr(pm), _ptr(uh), B,
+                                      CRC if crc else 0, HOST))
         return info, pm, uh
 
-    def mc_run(self, decoder, L, dtype, N0, seed, frame0, nframes, fast=True):
+    def mc_run(self, decoder, L, dtype, N0, seed, frame0, nframes, fast=True, crc=False):
         cnt = np.zeros(3, dtype=np.uint64)
-        _check(lib().polar_mc_run(self._h, decoder, L, _dt(dtype), SC_FAST if (fast and decoder == DEC_SC) else 0, float(N0),
+        flags = (SC_FAST if (fast and decoder == DEC_SC) else 0) | (CRC if crc else 0)
+        _check(lib().polar_mc_run(self._h, decoder, L, _dt(dtype), flags, float(N0),
                                   seed, frame0, nframes, cnt.ctypes.data))
         return cnt
 
     # ---- raw device-pointer entry points (used by bench.py / simulator with torch tensors) --------
-    def gen_frames_dev(self, info_ptr, llr_ptr, dtype, N0, seed, frame0, B):
-        _check(lib().polar_gen_frames(self._h, info_ptr, llr_ptr, _dt(dtype), float(N0), seed, frame0, B))
+    def gen_frames_dev(self, info_ptr, llr_ptr, dtype, N0, seed, frame0, B, crc=False):
+        _check(lib().polar_gen_frames(self._h, info_ptr, llr_ptr, _dt(dtype), float(N0), seed, frame0, B, CRC if crc else 0))
 
     def sc_decode_dev(self, llr_ptr, dtype, info_hat_ptr, B, fast=True, u_hat_ptr=None, dec_llr_ptr=None):
         _check(lib().polar_sc_decode_packed(self._h, llr_ptr, _dt(dtype), info_hat_ptr, u_hat_ptr, dec_llr_ptr, B,
                                             SC_FAST if fast else 0, DEVICE))
 
-    def scl_decode_dev(self, llr_ptr, dtype, L, info_hat_ptr, B, pm_ptr=None, u_hat_ptr=None):
-        _check(lib().polar_scl_decode_packed(self._h, llr_ptr, _dt(dtype), L, info_hat_ptr, pm_ptr, u_hat_ptr, B, DEVICE))
+    def scl_decode_dev(self, llr_ptr, dtype, L, info_hat_ptr, B, pm_ptr=None, u_hat_ptr=None, crc=False):
+        _check(lib().polar_scl_decode_packed(self._h, llr_ptr, _dt(dtype), L, info_hat_ptr, pm_ptr, u_hat_ptr, B,
+                                             CRC if crc else 0, DEVICE))
 
-    def count_errors_dev(self, info_ptr, hat_ptr, B, counters_ptr):
-        _check(lib().polar_count_errors(self._h, info_ptr, hat_ptr, B, counters_ptr))
+    def count_errors_dev(self, info_ptr, hat_ptr, B, counters_ptr, crc=False):
+        _check(lib().polar_count_errors(self._h, info_ptr, hat_ptr, B, CRC if crc else 0, counters_ptr))
 
 
 def schedule_build(mask, fast):

@@ -197,15 +197,19 @@ int launch_channel(polar_code *c, const uint32_t *xw, void *llr, int dtype, doub
 // ------------------------------------------------------------------------------------------ frame generator
 // info bits (Philox stream 0) -> rate profile -> butterfly (LDS) -> BPSK + AWGN -> LLR, one block per
 // `fpb` frames.  The K info bits are also written out (packed, zero padded) for the error counter.
+// With a CRC table (crcE != NULL) only the first Km = K - crc_w bits are random; the CRC of those, a GF(2)
+// linear map given per message bit by crcE, fills the last crc_w information bits.
 template <typename T>
 __global__ void __launch_bounds__(BLOCK) gen_frames_kernel(uint32_t *__restrict__ info_out, T *__restrict__ llr,
                                                           const uint32_t *__restrict__ maskw, const uint32_t *__restrict__ rank,
+                                                          const uint32_t *__restrict__ crcE, int Km, int crc_w,
                                                           int64_t B, int N, int Nw, int K, int Kw, int n, int fpb, T sigma, T gain,
                                                           uint64_t seed, uint64_t frame0)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t *xw = lds;               // fpb * Nw
     uint32_t *iw = lds + fpb * Nw;    // fpb * Kw
+    uint32_t *crcv = iw + fpb * Kw;   // fpb
     int64_t f0 = (int64_t)blockIdx.x * fpb;
     int nfr = (int)min((int64_t)fpb, B - f0);
     for (int idx = threadIdx.x; idx < nfr * Kw; idx += BLOCK) {
@@ -213,12 +217,33 @@ __global__ void __launch_bounds__(BLOCK) gen_frames_kernel(uint32_t *__restrict_
         uint32_t r[4];
         philox4x32_10(frame0 + (uint64_t)(f0 + fl), (uint32_t)(w >> 2), 0u, seed, r);
         uint32_t v = r[w & 3];
-        int valid = K - 32 * w;
+        int valid = Km - 32 * w;
         if (valid < 32) v = valid <= 0 ? 0u : (v & ((1u << valid) - 1u));
         iw[idx] = v;
-        if (info_out) info_out[(f0 + fl) * Kw + w] = v;
+        if (idx < nfr) crcv[idx] = 0u;
     }
     __syncthreads();
+    if (crcE) {
+        for (int idx = threadIdx.x; idx < nfr * Kw; idx += BLOCK) {
+            int fl = idx / Kw, w = idx - fl * Kw;
+            uint32_t v = iw[idx], acc = 0u;
+            while (v) {
+                acc ^= crcE[32 * w + __ffs(v) - 1];
+                v &= v - 1;
+            }
+            if (acc) atomicXor(&crcv[fl], acc);
+        }
+        __syncthreads();
+        for (int fl = threadIdx.x; fl < nfr; fl += BLOCK) {
+            const uint32_t c = crcv[fl];
+            const int sh = Km & 31;
+            iw[fl * Kw + (Km >> 5)] |= c << sh;
+            if (sh + crc_w > 32) iw[fl * Kw + (Km >> 5) + 1] |= c >> (32 - sh);
+        }
+        __syncthreads();
+    }
+    if (info_out)
+        for (int idx = threadIdx.x; idx < nfr * Kw; idx += BLOCK) info_out[f0 * Kw + idx] = iw[idx];
     int nwords = nfr * Nw;
     for (int idx = threadIdx.x; idx < nwords; idx += BLOCK) {
         int fl = idx / Nw, m = idx - fl * Nw;
@@ -245,32 +270,44 @@ __global__ void __launch_bounds__(BLOCK) gen_frames_kernel(uint32_t *__restrict_
     }
 }
 
-int launch_gen_frames(polar_code *c, uint32_t *info, void *llr, int dtype, double N0, uint64_t seed, uint64_t frame0, int64_t B)
+int launch_gen_frames(polar_code *c, uint32_t *info, void *llr, int dtype, double N0, uint64_t seed, uint64_t frame0, int64_t B,
+                      bool crc)
 {
     if (B == 0) return POLAR_OK;
     int fpb = frames_per_block(c->Nw);
     int64_t blocks = (B + fpb - 1) / fpb;
-    size_t lds = (size_t)fpb * (c->Nw + c->Kw) * 4;
+    size_t lds = (size_t)fpb * (c->Nw + c->Kw + 1) * 4;
     double sigma = sqrt(N0 / 2.0), gain = 4.0 / N0;
+    const uint32_t *crcE = crc ? c->d_crcE : nullptr;
+    const int crc_w = crc ? c->crc_w : 0, Km = c->K - crc_w;
     if (dtype == POLAR_F32)
         hipLaunchKernelGGL(gen_frames_kernel<float>, dim3((unsigned)blocks), dim3(BLOCK), lds, c->ctx->stream, info, (float *)llr,
-                           c->d_maskw, c->d_rank, B, c->N, c->Nw, c->K, c->Kw, c->n, fpb, (float)sigma, (float)gain, seed, frame0);
+                           c->d_maskw, c->d_rank, crcE, Km, crc_w, B, c->N, c->Nw, c->K, c->Kw, c->n, fpb, (float)sigma, (float)gain,
+                           seed, frame0);
     else
         hipLaunchKernelGGL(gen_frames_kernel<double>, dim3((unsigned)blocks), dim3(BLOCK), lds, c->ctx->stream, info, (double *)llr,
-                           c->d_maskw, c->d_rank, B, c->N, c->Nw, c->K, c->Kw, c->n, fpb, sigma, gain, seed, frame0);
+                           c->d_maskw, c->d_rank, crcE, Km, crc_w, B, c->N, c->Nw, c->K, c->Kw, c->n, fpb, sigma, gain, seed, frame0);
     HIP_TRY(hipGetLastError());
     return POLAR_OK;
 }
 
 // ------------------------------------------------------------------------------------------ error counter
+// Bits of word w (of a packed frame) that lie below bit index nbits of the frame.
+__device__ __forceinline__ uint32_t leading_bits_mask(int nbits, int w)
+{
+    int valid = nbits - 32 * w;
+    return valid >= 32 ? 0xFFFFFFFFu : (valid <= 0 ? 0u : ((1u << valid) - 1u));
+}
+
 // One lane per 32-bit word (coalesced); the words of a frame sit in Kw consecutive lanes (Kw a power of two
 // <= 64), so a frame's bit errors are a segmented butterfly sum over those lanes.
 __global__ void __launch_bounds__(BLOCK) count_errors_words_kernel(const uint32_t *__restrict__ info, const uint32_t *__restrict__ hat,
-                                                                  int64_t total_words, int Kw, unsigned long long *__restrict__ counters)
+                                                                  int64_t total_words, int Kw, int nbits,
+                                                                  unsigned long long *__restrict__ counters)
 {
     unsigned int be = 0, fe = 0, fr = 0;
     for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t - (threadIdx.x & 63) < total_words; t += (int64_t)gridDim.x * BLOCK) {
-        unsigned int e = t < total_words ? __popc(info[t] ^ hat[t]) : 0u;
+        unsigned int e = t < total_words ? __popc((info[t] ^ hat[t]) & leading_bits_mask(nbits, (int)(t & (Kw - 1)))) : 0u;
         for (int off = 1; off < Kw; off <<= 1) e += __shfl_xor(e, off);
         if ((t & (Kw - 1)) == 0 && t < total_words) {
             be += e;
@@ -292,12 +329,12 @@ __global__ void __launch_bounds__(BLOCK) count_errors_words_kernel(const uint32_
 
 // General case: one frame per lane.
 __global__ void __launch_bounds__(BLOCK) count_errors_kernel(const uint32_t *__restrict__ info, const uint32_t *__restrict__ hat,
-                                                            int64_t B, int Kw, unsigned long long *__restrict__ counters)
+                                                            int64_t B, int Kw, int nbits, unsigned long long *__restrict__ counters)
 {
     int64_t f = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     unsigned int be = 0;
     if (f < B)
-        for (int w = 0; w < Kw; w++) be += __popc(info[f * Kw + w] ^ hat[f * Kw + w]);
+        for (int w = 0; w < Kw; w++) be += __popc((info[f * Kw + w] ^ hat[f * Kw + w]) & leading_bits_mask(nbits, w));
     unsigned int fe = be > 0 ? 1u : 0u, fr = f < B ? 1u : 0u;
     for (int off = 32; off > 0; off >>= 1) {
         be += __shfl_down(be, off);
@@ -311,7 +348,7 @@ __global__ void __launch_bounds__(BLOCK) count_errors_kernel(const uint32_t *__r
     }
 }
 
-int launch_count_errors(polar_code *c, const uint32_t *info, const uint32_t *hat, int64_t B, uint64_t *counters)
+int launch_count_errors(polar_code *c, const uint32_t *info, const uint32_t *hat, int64_t B, uint64_t *counters, int nbits)
 {
     if (B == 0) return POLAR_OK;
     const int Kw = c->Kw;
@@ -319,10 +356,10 @@ int launch_count_errors(polar_code *c, const uint32_t *info, const uint32_t *hat
         int64_t total = B * Kw;
         int64_t blocks = std::min<int64_t>((total + BLOCK - 1) / BLOCK, (int64_t)c->ctx->num_cus * 16);
         hipLaunchKernelGGL(count_errors_words_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, c->ctx->stream, info, hat, total, Kw,
-                           (unsigned long long *)counters);
+                           nbits, (unsigned long long *)counters);
     } else {
         hipLaunchKernelGGL(count_errors_kernel, dim3((unsigned)((B + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->ctx->stream, info, hat, B,
-                           Kw, (unsigned long long *)counters);
+                           Kw, nbits, (unsigned long long *)counters);
     }
     HIP_TRY(hipGetLastError());
     return POLAR_OK;

@@ -26,6 +26,7 @@ template <typename T> struct SCLParams {
     const T *llr;
     const uint32_t *ops;
     const uint32_t *A;
+    const uint32_t *crcS;  // per information bit: its contribution to the CRC remainder; NULL = take the best path
     uint32_t *info_hat;
     double *pm;
     uint32_t *u_hat_all;
@@ -275,7 +276,23 @@ __global__ void __launch_bounds__(64) scl_decode_kernel(SCLParams<T> p, const ui
         if (p.info_hat) {
             // every group packs its own bits (the ballots are wave-wide); only the best path stores
             uint32_t *dst = p.info_hat + f * p.Kw;
-            const bool best = act && rank == 0;
+            int sel = 0;
+            if (p.crcS) {
+                // CRC-aided choice: first path in sorted order whose information word leaves a zero remainder
+                uint32_t syn = 0;
+                for (int k = sub; k < p.K; k += G) {
+                    uint32_t pos = p.A[k];
+                    if ((uw[pos >> 5] >> (pos & 31)) & 1u) syn ^= p.crcS[k];
+                }
+                for (int off = 1; off < G; off <<= 1) syn ^= shfl_u32(syn, lane ^ off);
+                if (lane == 0) surv[0] = 0u;
+                wave_sync();
+                if (sub == 0 && act && syn == 0u) atomicOr(&surv[0], 1u << rank);
+                wave_sync();
+                const uint32_t pass = surv[0];
+                sel = pass ? __ffs(pass) - 1 : 0;
+            }
+            const bool best = act && rank == sel;
             pack_bits_group<G>(
                 p.K, sub, grp,
                 [&](int k) {
@@ -293,7 +310,7 @@ __global__ void __launch_bounds__(64) scl_decode_kernel(SCLParams<T> p, const ui
 
 // ------------------------------------------------------------------------------------------ launch
 template <typename T, int L>
-static int launch_scl_t(polar_code *c, const void *llr, uint32_t *info_hat, double *pm, uint32_t *u_hat_all, int64_t B)
+static int launch_scl_t(polar_code *c, const void *llr, uint32_t *info_hat, double *pm, uint32_t *u_hat_all, int64_t B, bool crc)
 {
     polar_ctx *ctx = c->ctx;
     constexpr int G = 64 / L;
@@ -301,6 +318,7 @@ static int launch_scl_t(polar_code *c, const void *llr, uint32_t *info_hat, doub
     p.llr = (const T *)llr;
     p.ops = c->d_sched[0];
     p.A = c->d_A;
+    p.crcS = crc ? c->d_crcS : nullptr;
     p.info_hat = info_hat;
     p.pm = pm;
     p.u_hat_all = u_hat_all;
@@ -339,28 +357,29 @@ static int launch_scl_t(polar_code *c, const void *llr, uint32_t *info_hat, doub
 }
 
 template <typename T>
-static int launch_scl_l(polar_code *c, const void *llr, int L, uint32_t *info_hat, double *pm, uint32_t *u_hat_all, int64_t B)
+static int launch_scl_l(polar_code *c, const void *llr, int L, uint32_t *info_hat, double *pm, uint32_t *u_hat_all, int64_t B,
+                       bool crc)
 {
     switch (L) {
-    case 1: return launch_scl_t<T, 1>(c, llr, info_hat, pm, u_hat_all, B);
-    case 2: return launch_scl_t<T, 2>(c, llr, info_hat, pm, u_hat_all, B);
-    case 4: return launch_scl_t<T, 4>(c, llr, info_hat, pm, u_hat_all, B);
-    case 8: return launch_scl_t<T, 8>(c, llr, info_hat, pm, u_hat_all, B);
-    case 16: return launch_scl_t<T, 16>(c, llr, info_hat, pm, u_hat_all, B);
-    case 32: return launch_scl_t<T, 32>(c, llr, info_hat, pm, u_hat_all, B);
+    case 1: return launch_scl_t<T, 1>(c, llr, info_hat, pm, u_hat_all, B, crc);
+    case 2: return launch_scl_t<T, 2>(c, llr, info_hat, pm, u_hat_all, B, crc);
+    case 4: return launch_scl_t<T, 4>(c, llr, info_hat, pm, u_hat_all, B, crc);
+    case 8: return launch_scl_t<T, 8>(c, llr, info_hat, pm, u_hat_all, B, crc);
+    case 16: return launch_scl_t<T, 16>(c, llr, info_hat, pm, u_hat_all, B, crc);
+    case 32: return launch_scl_t<T, 32>(c, llr, info_hat, pm, u_hat_all, B, crc);
     default: polar_set_error("SCL decoder: unsupported list size %d", L); return POLAR_EINVAL;
     }
 }
 
 int launch_scl_decode(polar_code *c, const void *llr, int dtype, int L, uint32_t *info_hat, double *pm, uint32_t *u_hat_all,
-                      int64_t B)
+                      int64_t B, bool crc)
 {
     if (B == 0) return POLAR_OK;
     if (c->n > 12) {
         polar_set_error("SCL decoder: N=%d exceeds the supported maximum of 4096", c->N);
         return POLAR_EUNSUPPORTED;
     }
-    if (scl_reg_supported(c, dtype, L, pm, u_hat_all)) return launch_scl_reg(c, llr, info_hat, B);
-    if (dtype == POLAR_F32) return launch_scl_l<float>(c, llr, L, info_hat, pm, u_hat_all, B);
-    return launch_scl_l<double>(c, llr, L, info_hat, pm, u_hat_all, B);
+    if (scl_reg_supported(c, dtype, L, pm, u_hat_all)) return launch_scl_reg(c, llr, info_hat, B, crc);
+    if (dtype == POLAR_F32) return launch_scl_l<float>(c, llr, L, info_hat, pm, u_hat_all, B, crc);
+    return launch_scl_l<double>(c, llr, L, info_hat, pm, u_hat_all, B, crc);
 }

@@ -285,8 +285,8 @@ __device__ __forceinline__ void scl_node(SclReg<NLOG> &d, uint32_t maskv, const 
 
 template <int NLOG>
 __global__ void __launch_bounds__(64, 2) scl_reg_kernel(const float *__restrict__ llr, const uint32_t *__restrict__ maskw,
-                                                        const uint32_t *__restrict__ Asl8, uint32_t *__restrict__ info_hat, int64_t B,
-                                                        int K, int Kw)
+                                                        const uint32_t *__restrict__ Asl8, const uint32_t *__restrict__ crcS,
+                                                        uint32_t *__restrict__ info_hat, int64_t B, int K, int Kw)
 {
     __shared__ uint32_t surv[8];
     __shared__ uint32_t stage[64 * 4];  // 8 paths x 8 lanes x 128-bit slice of u_hat
@@ -348,13 +348,15 @@ __global__ void __launch_bounds__(64, 2) scl_reg_kernel(const float *__restrict_
         if (info_hat) {
             uint32_t *dst = info_hat + f * Kw;
             const uint32_t *mine = stage + lc.p * 32;
-            const bool best = act && rank == 0;
             uint32_t wout[4] = {0u, 0u, 0u, 0u};
+            uint32_t syn = 0u;  // this lane's share of the path's CRC remainder (stays 0 without a CRC)
             pack_bits_group<8>(
                 K, lc.q, lc.p,
                 [&](int k) {
                     const uint32_t a = Asl8[k];  // (lane-in-path << 7) | bit
-                    return ((mine[(a >> 7) * 4 + ((a >> 5) & 3u)] >> (a & 31u)) & 1u) != 0u;
+                    const bool bit = ((mine[(a >> 7) * 4 + ((a >> 5) & 3u)] >> (a & 31u)) & 1u) != 0u;
+                    if (crcS && bit) syn ^= crcS[k];
+                    return bit;
                 },
                 [&](int wi, uint32_t v) {
                     if ((wi & 7) == lc.q) {
@@ -364,6 +366,20 @@ __global__ void __launch_bounds__(64, 2) scl_reg_kernel(const float *__restrict_
                         else wout[3] = v;
                     }
                 });
+            int sel = 0;
+            if (crcS) {
+                // CRC-aided choice: first path in sorted order whose information word leaves a zero remainder
+                syn ^= partner8_u<2>(syn);
+                syn ^= partner8_u<4>(syn);
+                syn ^= partner8_u<8>(syn);
+                if (lc.lane == 0) surv[0] = 0u;
+                wave_sync();
+                if (lc.q == 0 && act && syn == 0u) atomicOr(&surv[0], 1u << rank);
+                wave_sync();
+                const uint32_t pass = surv[0];
+                sel = pass ? __ffs(pass) - 1 : 0;
+            }
+            const bool best = act && rank == sel;
             if (best) {
 #pragma unroll
                 for (int i = 0; i < 4; i++)
@@ -385,7 +401,7 @@ bool scl_reg_supported(const polar_code *c, int dtype, int L, const void *pm, co
     return true;
 }
 
-template <int NLOG> static int launch_scl_reg_t(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B)
+template <int NLOG> static int launch_scl_reg_t(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, bool crc)
 {
     polar_ctx *ctx = c->ctx;
     auto kern = scl_reg_kernel<NLOG>;
@@ -395,7 +411,7 @@ template <int NLOG> static int launch_scl_reg_t(polar_code *c, const void *llr, 
     int64_t grid = std::min<int64_t>(B, (int64_t)ctx->num_cus * occ * 8);
     LaunchTimer tm(ctx);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), 0, ctx->stream, (const float *)llr, (const uint32_t *)c->d_maskw,
-                       (const uint32_t *)c->d_Asl8, info_hat, B, c->K, c->Kw);
+                       (const uint32_t *)c->d_Asl8, crc ? (const uint32_t *)c->d_crcS : nullptr, info_hat, B, c->K, c->Kw);
     HIP_TRY(hipGetLastError());
     float ms = tm.stop();
     snprintf(c->last.kernel, sizeof(c->last.kernel), "scl_reg_kernel<%d>/L8", NLOG);
@@ -407,15 +423,15 @@ template <int NLOG> static int launch_scl_reg_t(polar_code *c, const void *llr, 
     return POLAR_OK;
 }
 
-int launch_scl_reg(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B)
+int launch_scl_reg(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, bool crc)
 {
     if (B == 0) return POLAR_OK;
     switch (c->n) {
-    case 6: return launch_scl_reg_t<6>(c, llr, info_hat, B);
-    case 7: return launch_scl_reg_t<7>(c, llr, info_hat, B);
-    case 8: return launch_scl_reg_t<8>(c, llr, info_hat, B);
-    case 9: return launch_scl_reg_t<9>(c, llr, info_hat, B);
-    case 10: return launch_scl_reg_t<10>(c, llr, info_hat, B);
+    case 6: return launch_scl_reg_t<6>(c, llr, info_hat, B, crc);
+    case 7: return launch_scl_reg_t<7>(c, llr, info_hat, B, crc);
+    case 8: return launch_scl_reg_t<8>(c, llr, info_hat, B, crc);
+    case 9: return launch_scl_reg_t<9>(c, llr, info_hat, B, crc);
+    case 10: return launch_scl_reg_t<10>(c, llr, info_hat, B, crc);
     default: polar_set_error("register SCL kernel: unsupported length"); return POLAR_EUNSUPPORTED;
     }
 }

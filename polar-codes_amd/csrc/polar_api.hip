@@ -209,7 +209,8 @@ extern "C" int polar_code_destroy(polar_code *c)
     if (!c) return POLAR_OK;
     (void)hipSetDevice(c->ctx->device);
     (void)hipStreamSynchronize(c->ctx->stream);
-    uint32_t *ps[] = {c->d_maskw, c->d_rank, c->d_A, c->d_sched[0], c->d_sched[1], c->d_sched[2], c->d_sched[3], c->d_Asl, c->d_Asl8};
+    uint32_t *ps[] = {c->d_maskw, c->d_rank, c->d_A, c->d_sched[0], c->d_sched[1], c->d_sched[2], c->d_sched[3], c->d_Asl, c->d_Asl8,
+                      c->d_crcE, c->d_crcS};
     for (uint32_t *p : ps)
         if (p) (void)hipFree(p);
     delete c;
@@ -221,6 +222,51 @@ extern "C" int polar_code_schedule_len(const polar_code *c, int which)
 {
     return (c && which >= 0 && which < 4) ? (int)c->sched[which].size() : 0;
 }
+extern "C" int polar_code_crc_width(const polar_code *c) { return c ? c->crc_w : 0; }
+
+extern "C" int polar_code_set_crc(polar_code *c, uint64_t crc_poly)
+{
+    ARG_TRY(c != nullptr, "code is NULL");
+    HIP_TRY(hipSetDevice(c->ctx->device));
+    HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+    if (c->d_crcE) (void)hipFree(c->d_crcE);
+    if (c->d_crcS) (void)hipFree(c->d_crcS);
+    c->d_crcE = c->d_crcS = nullptr;
+    c->crc_poly = 0;
+    c->crc_w = 0;
+    if (crc_poly == 0) return POLAR_OK;
+    int w = 63 - __builtin_clzll(crc_poly);
+    ARG_TRY(w >= 1 && w <= 32, "CRC width (degree of crc_poly) must be in [1, 32]");
+    ARG_TRY(w <= c->K, "CRC is wider than the code's information length");
+    const uint64_t keep = (w == 64) ? ~0ull : ((1ull << w) - 1ull);
+    const uint64_t low = crc_poly & keep;
+    // R[p] = x^(p + w) mod g: what a one at distance p from the end of a word leaves in the remainder register
+    // of the MSB-first shift register after the word and w zeros went through (cn/functions.py:567-583)
+    std::vector<uint32_t> R(c->K);
+    uint64_t r = low;
+    for (int p = 0; p < c->K; p++) {
+        R[p] = (uint32_t)r;
+        const uint64_t top = (r >> (w - 1)) & 1ull;
+        r = ((r << 1) & keep) ^ (top ? low : 0ull);
+    }
+    const int Km = c->K - w;
+    std::vector<uint32_t> E(std::max(1, Km), 0), S(c->K);
+    for (int k = 0; k < Km; k++) {
+        uint32_t v = R[Km - 1 - k], t = 0;  // appended bit j is register bit w-1-j
+        for (int j = 0; j < w; j++) t |= ((v >> (w - 1 - j)) & 1u) << j;
+        E[k] = t;
+    }
+    for (int k = 0; k < c->K; k++) S[k] = R[c->K - 1 - k];
+    HIP_TRY(hipMalloc((void **)&c->d_crcE, E.size() * 4));
+    HIP_TRY(hipMalloc((void **)&c->d_crcS, S.size() * 4));
+    HIP_TRY(hipMemcpy(c->d_crcE, E.data(), E.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_crcS, S.data(), S.size() * 4, hipMemcpyHostToDevice));
+    c->crc_poly = crc_poly;
+    c->crc_w = w;
+    return POLAR_OK;
+}
+#define CRC_TRY(c, flags) ARG_TRY(!((flags)&POLAR_CRC) || (c)->crc_w > 0, "POLAR_CRC needs polar_code_set_crc first")
+
 extern "C" int polar_last_launch(polar_code *c, polar_launch_info *out)
 {
     ARG_TRY(c && out, "NULL argument");
@@ -332,13 +378,14 @@ extern "C" int polar_channel_llr(polar_code *c, const uint8_t *x, void *llr, int
 }
 
 extern "C" int polar_gen_frames(polar_code *c, uint32_t *info, void *llr, int dtype, double N0, uint64_t seed,
-                                uint64_t frame0, int64_t B)
+                                uint64_t frame0, int64_t B, int flags)
 {
     CHECK_COMMON(c, B, POLAR_DEVICE);
+    CRC_TRY(c, flags);
     ARG_TRY(llr != nullptr, "llr is NULL");
     ARG_TRY(dtype == POLAR_F32 || dtype == POLAR_F64, "dtype must be POLAR_F32 or POLAR_F64");
     ARG_TRY(N0 > 0, "N0 must be positive");
-    return launch_gen_frames(c, info, llr, dtype, N0, seed, frame0, B);
+    return launch_gen_frames(c, info, llr, dtype, N0, seed, frame0, B, (flags & POLAR_CRC) != 0);
 }
 
 // ---------------------------------------------------------------------------------------------- SC
@@ -414,16 +461,18 @@ extern "C" int polar_sc_decode_packed(polar_code *c, const void *llr, int dtype,
 
 // ---------------------------------------------------------------------------------------------- SCL
 static int scl_common(polar_code *c, const void *llr, int dtype, int L, void *info_hat, double *pm,
-                      void *u_hat_all, int64_t B, int space, bool packed)
+                      void *u_hat_all, int64_t B, int flags, int space, bool packed)
 {
     CHECK_COMMON(c, B, space);
+    CRC_TRY(c, flags);
+    const bool crc = (flags & POLAR_CRC) != 0;
     ARG_TRY(llr != nullptr, "llr is NULL");
     ARG_TRY(dtype == POLAR_F32 || dtype == POLAR_F64, "dtype must be POLAR_F32 or POLAR_F64");
     ARG_TRY(L == 1 || L == 2 || L == 4 || L == 8 || L == 16 || L == 32, "L must be a power of two in [1, 32]");
     polar_ctx *ctx = c->ctx;
     const size_t es = llr_size(dtype);
     if (space == POLAR_DEVICE && packed)
-        return launch_scl_decode(c, llr, dtype, L, (uint32_t *)info_hat, pm, (uint32_t *)u_hat_all, B);
+        return launch_scl_decode(c, llr, dtype, L, (uint32_t *)info_hat, pm, (uint32_t *)u_hat_all, B, crc);
     int rc;
     const int64_t chunk = (space == POLAR_HOST) ? std::max<int64_t>(1, HOST_CHUNK / L) : (int64_t)1 << 18;
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
@@ -439,7 +488,7 @@ static int scl_common(polar_code *c, const void *llr, int dtype, int L, void *in
             HIP_TRY(hipMemcpyAsync(ctx->llr_buf.p, dl, nb * c->N * es, hipMemcpyHostToDevice, ctx->stream));
             dl = ctx->llr_buf.as<char>();
         }
-        if ((rc = launch_scl_decode(c, dl, dtype, L, wi, dpm, wu, nb))) return rc;
+        if ((rc = launch_scl_decode(c, dl, dtype, L, wi, dpm, wu, nb, crc))) return rc;
         if (packed) {
             if (info_hat) HIP_TRY(hipMemcpyAsync((uint32_t *)info_hat + b0 * c->Kw, wi, nb * c->Kw * 4, hipMemcpyDeviceToHost, ctx->stream));
             if (u_hat_all) HIP_TRY(hipMemcpyAsync((uint32_t *)u_hat_all + b0 * L * c->Nw, wu, nb * L * c->Nw * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -471,22 +520,24 @@ static int scl_common(polar_code *c, const void *llr, int dtype, int L, void *in
 }
 
 extern "C" int polar_scl_decode(polar_code *c, const void *llr, int dtype, int L, uint8_t *info_hat, double *pm,
-                                uint8_t *u_hat_all, int64_t B, int space)
+                                uint8_t *u_hat_all, int64_t B, int flags, int space)
 {
-    return scl_common(c, llr, dtype, L, info_hat, pm, u_hat_all, B, space, false);
+    return scl_common(c, llr, dtype, L, info_hat, pm, u_hat_all, B, flags, space, false);
 }
 extern "C" int polar_scl_decode_packed(polar_code *c, const void *llr, int dtype, int L, uint32_t *info_hat,
-                                       double *pm, uint32_t *u_hat_all, int64_t B, int space)
+                                       double *pm, uint32_t *u_hat_all, int64_t B, int flags, int space)
 {
-    return scl_common(c, llr, dtype, L, info_hat, pm, u_hat_all, B, space, true);
+    return scl_common(c, llr, dtype, L, info_hat, pm, u_hat_all, B, flags, space, true);
 }
 
 // ---------------------------------------------------------------------------------------------- counting / MC
-extern "C" int polar_count_errors(polar_code *c, const uint32_t *info, const uint32_t *hat, int64_t B, uint64_t *counters)
+extern "C" int polar_count_errors(polar_code *c, const uint32_t *info, const uint32_t *hat, int64_t B, int flags,
+                                  uint64_t *counters)
 {
     CHECK_COMMON(c, B, POLAR_DEVICE);
+    CRC_TRY(c, flags);
     ARG_TRY(info && hat && counters, "NULL buffer");
-    return launch_count_errors(c, info, hat, B, counters);
+    return launch_count_errors(c, info, hat, B, counters, (flags & POLAR_CRC) ? c->K - c->crc_w : c->K);
 }
 
 extern "C" int polar_mc_run(polar_code *c, int decoder, int L, int dtype, int flags, double N0, uint64_t seed,
@@ -499,6 +550,9 @@ extern "C" int polar_mc_run(polar_code *c, int decoder, int L, int dtype, int fl
     ARG_TRY(N0 > 0, "N0 must be positive");
     if (decoder == POLAR_DEC_SCL)
         ARG_TRY(L == 1 || L == 2 || L == 4 || L == 8 || L == 16 || L == 32, "L must be a power of two in [1, 32]");
+    CRC_TRY(c, flags);
+    ARG_TRY(!((flags & POLAR_CRC) && decoder != POLAR_DEC_SCL), "POLAR_CRC goes with the list decoder");
+    const bool crc = (flags & POLAR_CRC) != 0;
     polar_ctx *ctx = c->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     if (nframes == 0) return POLAR_OK;
@@ -514,13 +568,15 @@ extern "C" int polar_mc_run(polar_code *c, int decoder, int L, int dtype, int fl
     HIP_TRY(hipMemsetAsync(dcnt, 0, 3 * sizeof(uint64_t), ctx->stream));
     for (int64_t f0 = 0; f0 < nframes; f0 += chunk) {
         int64_t nb = std::min(chunk, nframes - f0);
-        if ((rc = launch_gen_frames(c, ctx->mc_info.as<uint32_t>(), ctx->llr_buf.p, dtype, N0, seed, frame0 + f0, nb))) return rc;
+        if ((rc = launch_gen_frames(c, ctx->mc_info.as<uint32_t>(), ctx->llr_buf.p, dtype, N0, seed, frame0 + f0, nb, crc))) return rc;
         if (decoder == POLAR_DEC_SC)
             rc = launch_sc_decode(c, ctx->llr_buf.p, dtype, ctx->mc_hat.as<uint32_t>(), nullptr, nullptr, nb, flags);
         else
-            rc = launch_scl_decode(c, ctx->llr_buf.p, dtype, L, ctx->mc_hat.as<uint32_t>(), nullptr, nullptr, nb);
+            rc = launch_scl_decode(c, ctx->llr_buf.p, dtype, L, ctx->mc_hat.as<uint32_t>(), nullptr, nullptr, nb, crc);
         if (rc) return rc;
-        if ((rc = launch_count_errors(c, ctx->mc_info.as<uint32_t>(), ctx->mc_hat.as<uint32_t>(), nb, dcnt))) return rc;
+        if ((rc = launch_count_errors(c, ctx->mc_info.as<uint32_t>(), ctx->mc_hat.as<uint32_t>(), nb, dcnt,
+                                      crc ? c->K - c->crc_w : c->K)))
+            return rc;
     }
     uint64_t h[3];
     HIP_TRY(hipMemcpyAsync(h, dcnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));

@@ -86,6 +86,11 @@ struct polar_code {
     uint32_t *d_sched[4] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t *d_Asl8 = nullptr;    // same for the 8-lanes-per-path layout: (lane-in-path << 7) | bit
     uint32_t *d_Asl = nullptr;     // K entries: (lane << 6) | bit of each info position in the sliced layout
+    // CRC (0 = none): generator with leading term, degree, and the two linear maps of the remainder
+    uint64_t crc_poly = 0;
+    int crc_w = 0;
+    uint32_t *d_crcE = nullptr;    // K - crc_w words: CRC bits (bit j = j-th appended bit) contributed by message bit k
+    uint32_t *d_crcS = nullptr;    // K words: remainder contributed by bit k of the K-bit word (message + CRC)
     polar_launch_info last{};
 };
 
@@ -96,16 +101,17 @@ int launch_encode(polar_code *c, const uint32_t *info_or_u, uint32_t *x, int64_t
 int launch_channel(polar_code *c, const uint32_t *xw, void *llr, int dtype, double N0, uint64_t seed,
                    uint64_t frame0, int64_t B);
 int launch_gen_frames(polar_code *c, uint32_t *info, void *llr, int dtype, double N0, uint64_t seed,
-                      uint64_t frame0, int64_t B);
+                      uint64_t frame0, int64_t B, bool crc);
 int launch_sc_decode(polar_code *c, const void *llr, int dtype, uint32_t *info_hat, uint32_t *u_hat,
                      void *dec_llr, int64_t B, int flags);
 bool sc_reg_supported(const polar_code *c, int dtype, const void *u_hat, const void *dec_llr);
 int launch_sc_reg(polar_code *c, const void *llr, int dtype, uint32_t *info_hat, int64_t B, int flags);
 bool scl_reg_supported(const polar_code *c, int dtype, int L, const void *pm, const void *u_hat_all);
-int launch_scl_reg(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B);
+int launch_scl_reg(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, bool crc);
 int launch_scl_decode(polar_code *c, const void *llr, int dtype, int L, uint32_t *info_hat, double *pm,
-                      uint32_t *u_hat_all, int64_t B);
-int launch_count_errors(polar_code *c, const uint32_t *info, const uint32_t *hat, int64_t B, uint64_t *counters);
+                      uint32_t *u_hat_all, int64_t B, bool crc);
+// nbits: leading bits of each K-bit word that are compared
+int launch_count_errors(polar_code *c, const uint32_t *info, const uint32_t *hat, int64_t B, uint64_t *counters, int nbits);
 
 // timing bracket around the dominant kernel of a call
 struct LaunchTimer {

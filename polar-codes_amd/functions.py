@@ -157,3 +157,73 @@ def GN(N: int, Fn=None):
     for _ in range(int(math.log2(N))):
         G = np.kron(G, F)
     return G
+
+
+# ---------------- CRC (for CRC-aided list decoding) ----------------
+
+def standardForm(crcPoly):
+    """Coefficients of the generator polynomial below its leading term, MSB first, and the same as a hex string
+    (cn/functions.py:83-92).  0x107 -> [0,0,0,0,0,1,1,1], '0x007'."""
+    bits = bin(crcPoly)[3:]
+    arrayForm = np.array([int(b) for b in bits])
+    num = int(bits, 2) if bits else 0
+    return arrayForm, "0x" + hex(num)[2:].zfill(len(hex(crcPoly)) - len(hex(num)))
+
+
+def crcRemainder(message, crcPoly):
+    """Remainder register after shifting message + width zeros through the MSB-first LFSR of
+    cn/functions.py:567-583, as integers (one per row of `message`)."""
+    poly, _ = standardForm(crcPoly)
+    w = len(poly)
+    pint = int("".join(str(int(b)) for b in poly), 2) if w else 0
+    msg = np.atleast_2d(np.asarray(message)).astype(np.uint64)
+    reg = np.zeros(msg.shape[0], dtype=np.uint64)
+    top_shift, keep = np.uint64(max(w - 1, 0)), np.uint64((1 << w) - 1)
+    one = np.uint64(1)
+    for i in range(msg.shape[1] + w):
+        bit = msg[:, i] if i < msg.shape[1] else np.zeros(msg.shape[0], dtype=np.uint64)
+        top = (reg >> top_shift) & one
+        reg = ((reg << one) & keep) | bit
+        reg ^= top * np.uint64(pint)
+    return reg, w
+
+
+def crcEncode(message, crcPoly):
+    """message followed by its CRC remainder (cn/functions.py:567-583).  Accepts a leading batch axis."""
+    message = np.asarray(message)
+    reg, w = crcRemainder(message, crcPoly)
+    tail = ((reg[:, None] >> np.arange(w - 1, -1, -1, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(int)
+    out = np.concatenate([np.atleast_2d(message).astype(int), tail], axis=1)
+    return out[0] if message.ndim == 1 else out
+
+
+def crcCheck(word, crcPoly):
+    """True where a word (message + CRC) passes the reference's test: the remainder of crcEncode(word) is all
+    zero (cn/polarCode.py:2083-2087)."""
+    reg, _ = crcRemainder(word, crcPoly)
+    ok = reg == 0
+    return bool(ok[0]) if np.asarray(word).ndim == 1 else ok
+
+
+def polynomialMod(a, b):
+    """Remainder of a(x) / b(x) over GF(2), coefficient arrays MSB first, without b's leading position
+    (cn/functions.py:54-70)."""
+    a = [int(v) & 1 for v in a]
+    b = [int(v) & 1 for v in b]
+    for i in range(len(a) - len(b) + 1):
+        if a[i]:
+            for j, bj in enumerate(b):
+                a[i + j] ^= bj
+    return np.array(a[len(a) - len(b) + 1:], dtype=int)
+
+
+def getGC(KI, g):
+    """Systematic CRC generator matrix [I | parity] for KI message bits and generator coefficients g (MSB first,
+    leading one included) -- cn/functions.py:536-547."""
+    KC = len(g) - 1
+    right = np.zeros((KI, KC), dtype=int)
+    for i in range(KI):
+        x = np.zeros(KC + KI - i, dtype=int)
+        x[0] = 1
+        right[i, :] = polynomialMod(x, g)
+    return np.concatenate([np.eye(KI, dtype=int), right], axis=1)

@@ -68,6 +68,8 @@ class PolarCode:
         self.D = stackSize
         self.L = listSize
         self.isCRC = False
+        self.crcPoly = 0x0
+        self.crcPolyArrayForm = []
         self.crcWidth = 0
         self.decoderType = "sc"
         self.dtype = np.float64  # arithmetic type of the decoders: float64 = parity with the reference
@@ -133,6 +135,15 @@ class PolarCode:
         x = self.native.encode(info.reshape(int(np.prod(info.shape[:-1], dtype=np.int64)), self.infoLen))
         return x.reshape(info.shape[:-1] + (self.codewordLength,)).astype(int)
 
+    def CRCPolarEncode2(self, info):
+        """Append the CRC of self.crcPoly to the message, then polar-encode (cn/polarCode.py:265-271)."""
+        return self.polarEncode(pcfun.crcEncode(info, self.crcPoly))
+
+    def CRCPolarEncode(self, info):
+        """Systematic CRC through the generator matrix of self.crcPolyArrayForm (cn/polarCode.py:273-280)."""
+        GC = pcfun.getGC(self.infoLen - self.crcWidth, self.crcPolyArrayForm)
+        return self.polarEncode(np.dot(np.asarray(info), GC) % 2)
+
     def extract(self, uHat):
         """uHat[polarMask == 1] in index order (cn/polarCode.py:305-312)."""
         return np.asarray(uHat)[..., self.polarMask == 1].astype(int)
@@ -175,12 +186,15 @@ class PolarCode:
         """List decoding with list size self.L (cn/polarCode.py:2032-2102, 969-1005).  Sets self.pathList
         (survivors sorted by metric, descending, ties in the reference's stable order), self.ANV,
         self.sortNum, self.unitCal; returns the information bits of the best path."""
-        if isCRC or isRCPP:
-            raise NotImplementedError("CRC-aided selection and puncturing are not provided")
+        if isRCPP:
+            raise NotImplementedError("puncturing is not provided")
         L = int(self.L)
         llr = self._llr(softMess)
         batch = llr.shape[:-1]
-        info, pm, uh = self._active.scl_decode(llr.reshape(-1, self.codewordLength), L, want_list=True)
+        crc_dev = bool(isCRC) and not self.bitReversed
+        if crc_dev:
+            self._attach_crc()
+        info, pm, uh = self._active.scl_decode(llr.reshape(-1, self.codewordLength), L, want_list=True, crc=crc_dev)
         if self.bitReversed:
             uh = uh[:, :, self._rev]
             info = uh[:, 0][:, self.polarMask == 1]
@@ -191,7 +205,27 @@ class PolarCode:
             self.pathList = [[Path(uh[b, j].astype(int), pm[b, j]) for j in range(nsurv)] for b in range(uh.shape[0])]
         self.pathMetrics = pm.reshape(batch + (L,))
         self.ANV, self.sortNum, self.unitCal = self._scl_counts(L)
+        if crc_dev:
+            # the GPU picked the first survivor, in list order, whose information word passes the CRC, else the
+            # best one; the CRC bits are dropped from the result (cn/polarCode.py:2079-2097)
+            return info[:, :self.infoLen - self.crcWidth].reshape(batch + (self.infoLen - self.crcWidth,)).astype(int)
+        if isCRC:
+            # bit-reversed ordering: the same choice made here from the list the GPU returned
+            words = uh[:, :, self.polarMask == 1]                       # [B, L, K]
+            ok = pcfun.crcCheck(words.reshape(-1, self.infoLen), self.crcPoly).reshape(words.shape[:2])
+            ok[:, nsurv:] = False
+            pick = np.where(ok.any(axis=1), ok.argmax(axis=1), 0)
+            chosen = words[np.arange(words.shape[0]), pick][:, :self.infoLen - self.crcWidth]
+            return chosen.reshape(batch + (self.infoLen - self.crcWidth,)).astype(int)
         return info.reshape(batch + (self.infoLen,)).astype(int)
+
+    def _attach_crc(self):
+        """Hand self.crcPoly to the device code object (once per polynomial)."""
+        if pcfun.standardForm(self.crcPoly)[0].size != self.crcWidth:
+            raise ValueError("crcWidth %d does not match crcPoly %#x" % (self.crcWidth, self.crcPoly))
+        if getattr(self.native, "_crc_poly", None) != self.crcPoly:
+            self.native.set_crc(self.crcPoly)
+            self.native._crc_poly = self.crcPoly
 
     def _scl_counts(self, L):
         """Complexity counters of the reference's sclDecoder in closed form: they depend only on the

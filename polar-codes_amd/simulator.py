@@ -66,21 +66,23 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def native_runner(pcode, decoder, L, dtype):
+def native_runner(pcode, decoder, L, dtype, crc=False):
     """Default frame runner: polar_mc_run of the GPU library."""
     import _native
 
     dec = _native.DEC_SCL if decoder == "scl" else _native.DEC_SC
+    if crc:
+        pcode._attach_crc()
 
     def run(N0, seed, frame0, nframes):
-        return pcode.native.mc_run(dec, L, dtype, N0, seed, frame0, nframes)
+        return pcode.native.mc_run(dec, L, dtype, N0, seed, frame0, nframes, crc=crc)
 
     return run
 
 
 def simulate(pcode, snrRange, frames=None, errCnt=100, minFrames=100000, maxFrames=10 ** 8, seed=2024, decoder=None,
              L=None, dtype=np.float32, batch=1 << 18, snrType=None, modu=None, verbose=True, dist=None, runner=None,
-             reduce_device=None):
+             reduce_device=None, isCRC=None):
     """Eb/N0 (or Es/N0) sweep.
 
     frames=int   -> exactly that many frames per SNR point (split evenly over the ranks);
@@ -88,7 +90,10 @@ def simulate(pcode, snrRange, frames=None, errCnt=100, minFrames=100000, maxFram
                     (cn/simulator.py:257, errCnt=100, t >= 99999), tested after every round of
                     world_size * batch frames, so a point may overshoot by less than one round.
     decoder/L/snrType/modu default to the attributes set on `pcode` like the reference's driver does
-    (cn/simulator.py:78-83).  Returns a BERFER; every rank returns the same totals.
+    (cn/simulator.py:78-83).  isCRC (default pcode.isCRC) runs CRC-aided list decoding: pcode.infoLen then
+    counts the CRC bits (the reference's K2 = K + crcWidth, cn/simulator.py:22,75), the message has
+    infoLen - crcWidth bits, and rate and BER refer to the message (cn/simulator.py:20,133,360).
+    Returns a BERFER; every rank returns the same totals.
     """
     rank, world, dist = _dist_state(dist)
     decoder = (decoder or getattr(pcode, "decoderType", "sc") or "sc").lower()
@@ -97,8 +102,12 @@ def simulate(pcode, snrRange, frames=None, errCnt=100, minFrames=100000, maxFram
     L = int(L if L is not None else (getattr(pcode, "L", 0) or 1))
     snrType = snrType or getattr(pcode, "snrType", "") or "SNRb"
     modu = modu or getattr(pcode, "modu", "") or "BPSK"
-    rate = pcode.infoLen / pcode.codewordLength
-    run = runner or native_runner(pcode, decoder, L, dtype)
+    isCRC = bool(getattr(pcode, "isCRC", False) if isCRC is None else isCRC)
+    if isCRC and decoder != "scl":
+        raise ValueError("isCRC needs the list decoder")
+    msgLen = pcode.infoLen - (pcode.crcWidth if isCRC else 0)
+    rate = msgLen / pcode.codewordLength
+    run = runner or native_runner(pcode, decoder, L, dtype, crc=isCRC)
     if reduce_device is None:
         reduce_device = "cpu"
         if dist is not None and dist.get_backend() == "nccl":
@@ -135,7 +144,7 @@ def simulate(pcode, snrRange, frames=None, errCnt=100, minFrames=100000, maxFram
         if verbose and rank == 0:
             print(f"\nAt {snr} dB FER is {fe / max(nfr, 1):0.2e}")
         result.snrRange.append(snr)
-        result.ber.append(be / max(nfr * pcode.infoLen, 1))
+        result.ber.append(be / max(nfr * msgLen, 1))
         result.fer.append(fe / max(nfr, 1))
         result.frames.append(nfr)
         result.frameErrors.append(fe)
@@ -164,6 +173,9 @@ def main(argv=None):
     ap.add_argument("--minFrames", type=int, default=100000)
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--f64", action="store_true")
+    ap.add_argument("--crc", type=lambda s: int(s, 0), default=0,
+                    help="CRC generator with its leading term, e.g. 0x107; K then counts message bits and the code "
+                         "carries K + width information bits (cn/simulator.py:22)")
     a = ap.parse_args(argv)
     dist = None
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
@@ -172,8 +184,10 @@ def main(argv=None):
 
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group("nccl")
-    pc = PolarCode(a.N, a.K, a.construct, a.dsnr, listSize=a.L)
+    width = max(a.crc.bit_length() - 1, 0)
+    pc = PolarCode(a.N, a.K + width, a.construct, a.dsnr, listSize=a.L)
     pc.decoderType, pc.snrType, pc.modu = a.decoder, "SNRb", "BPSK"
+    pc.crcPoly, pc.crcWidth, pc.isCRC = a.crc, width, width > 0
     res = simulate(pc, a.snr, frames=a.frames, errCnt=a.errCnt, minFrames=a.minFrames, seed=a.seed,
                    dtype=np.float64 if a.f64 else np.float32, dist=dist)
     if dist is None or dist.get_rank() == 0:

@@ -349,7 +349,52 @@ def gen_mainflow(functions, polarCode, channel):
     print("mainflow:", len(out), "arrays; last frame correct:", bool((main.message == main.decoded).all()))
 
 
-SECTIONS = {"masks": gen_masks, "encoder": gen_encoder, "channel": gen_channel, "sc": gen_sc, "scl": gen_scl, "curves": gen_curves, "mainflow": gen_mainflow}
+# --------------------------------------------------------------------------- CRC-aided list decoding
+def gen_cascl(functions, polarCode, channel):
+    out = {}
+    rs = np.random.RandomState(42)
+    for poly, name in [(0x107, "crc8"), (0x1800063, "crc24"), (0x1621, "crc12")]:
+        m = rs.randint(0, 2, size=(6, 40)).astype(int)
+        out[f"{name}_msg"] = packbits(m)
+        out[f"{name}_enc"] = packbits(np.stack([functions.crcEncode(r.copy(), poly) for r in m]))
+        out[f"{name}_std"] = np.asarray(functions.standardForm(poly)[0], dtype=np.uint8)
+    g = np.array([1, 0, 0, 0, 0, 0, 1, 1, 1])
+    out["getGC_20_crc8"] = np.asarray(functions.getGC(20, g), dtype=np.uint8)
+    cfgs = [(128, 64, 0x107, 8, 4, 1.0, 80), (256, 128, 0x107, 8, 8, 1.0, 60), (1024, 536, 0x1800063, 24, 8, 1.0, 24)]
+    for (N, K, poly, w, L, snr, nfr) in cfgs:
+        pc = make_code(polarCode, functions, N, K, "dega", 2.0)
+        pc.L, pc.crcPoly, pc.crcWidth = L, poly, w
+        ch = channel.Channel("BPSK", snr, "SNRb", (K - w) / N)
+        tag = f"{N}_{K}_w{w}_L{L}"
+        seeds, decs, xs, nerr, plain = [], [], [], [], []
+        t0 = time.time()
+        for f in range(nfr):
+            seed = 31000 + 7 * f + N
+            np.random.seed(seed)
+            msg = np.random.randint(0, 2, size=K - w, dtype=int)
+            x = pc.CRCPolarEncode2(msg)
+            y = ch.addNoise(ch.modulate(x))
+            llr = ch.calcLLR(y)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                dec = pc.sclDecoder(llr.copy(), isCRC=True)
+                first = pc.extract(pc.pathList[0].uHat)[:K - w]
+            seeds.append(seed)
+            decs.append(packbits(dec))
+            xs.append(packbits(x))
+            nerr.append(int(np.sum(np.abs(msg - dec))))
+            plain.append(int(np.sum(np.abs(msg - first))))
+        out[f"{tag}_seeds"] = np.array(seeds, dtype=np.int64)
+        out[f"{tag}_dec"] = np.stack(decs)
+        out[f"{tag}_x"] = np.stack(xs)
+        out[f"{tag}_biterr"] = np.array(nerr, dtype=np.int64)
+        out[f"{tag}_biterr_first_path"] = np.array(plain, dtype=np.int64)
+        print(f"cascl {tag}: {nfr} frames, {sum(e > 0 for e in nerr)} frame errors with CRC selection, "
+              f"{sum(e > 0 for e in plain)} with the first path, {time.time()-t0:.1f}s", flush=True)
+    np.savez_compressed(os.path.join(OUT, "cascl.npz"), **out)
+
+
+SECTIONS = {"masks": gen_masks, "encoder": gen_encoder, "channel": gen_channel, "sc": gen_sc, "scl": gen_scl, "curves": gen_curves, "mainflow": gen_mainflow, "cascl": gen_cascl}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
