@@ -319,6 +319,27 @@ def main():
             del l16k, h16k
         except _native.PolarError as e:
             extras["other_configs_error"] = str(e)
+        # CRC-aided list decoding on the configuration cn/simulator.py:12-22 sets: 512 message bits + CRC-24, L = 8
+        try:
+            mca = pcf.degaBuild(1024, 512 + 24, 2.0)
+            cca = _native.Code(ctx, mca)
+            cca.set_crc(0x1800063)
+            nb = 1 << 20
+            ica = torch.empty((nb, cca.Kw), dtype=torch.int32, device=dev)
+            hca = torch.empty_like(ica)
+            lca = torch.empty((nb, 1024), dtype=torch.float32, device=dev)
+            cca.gen_frames_dev(ica.data_ptr(), lca.data_ptr(), np.float32, ch.noisePower, seed, 0, nb, crc=True)
+            cca.scl_decode_dev(lca.data_ptr(), np.float32, 8, hca.data_ptr(), nb, crc=True)
+            li = cca.last_launch()
+            c3 = torch.zeros(3, dtype=torch.int64, device=dev)
+            cca.count_errors_dev(ica.data_ptr(), hca.data_ptr(), nb, c3.data_ptr(), crc=True)
+            ctx.sync()
+            c3 = c3.cpu().tolist()
+            extras["ca_scl8_1024_512_crc24"] = {"frames_per_s": nb / (li["last_ms"] * 1e-3), "info_mbps": nb * 512 / (li["last_ms"] * 1e-3) / 1e6,
+                                                "kernel": li["kernel"], "kernel_ms": li["last_ms"], "frames": nb, "fer": c3[1] / nb}
+            del ica, hca, lca
+        except _native.PolarError as e:
+            extras["ca_scl8_1024_512_crc24"] = {"error": str(e)}
         ctx.enable_timing(False)
         # fused Monte-Carlo pipeline (generate + decode + count), nothing resident beforehand
         t0 = time.perf_counter()
