@@ -46,8 +46,10 @@ enum {
     POLAR_SC_FAST = 1,   /* polar_sc_decode*, polar_mc_run: skip all-frozen subtrees and hard-decide
                             all-information subtrees (same decisions as plain SC; decision LLRs are then
                             not available) */
-    POLAR_CRC = 2        /* polar_gen_frames, polar_scl_decode*, polar_count_errors, polar_mc_run: the last
+    POLAR_CRC = 2,       /* polar_gen_frames, polar_scl_decode*, polar_count_errors, polar_mc_run: the last
                             `width` information bits are the CRC set with polar_code_set_crc */
+    POLAR_GENIE = 4      /* polar_mc_run with POLAR_DEC_SCL: the genie-aided list decoder (polar_scl_decode_genie);
+                            not together with POLAR_CRC */
 };
 
 const char *polar_last_error(void);
@@ -126,6 +128,18 @@ int polar_scl_decode(polar_code *code, const void *llr, int dtype, int L, uint8_
 int polar_scl_decode_packed(polar_code *code, const void *llr, int dtype, int L, uint32_t *info_hat,
                             double *pm_sorted, uint32_t *u_hat_all, int64_t B, int flags, int space);
 
+/* ---- genie-aided list decoder: PolarCode.sclDecoderOracle (cn/polarCode.py:1267-1317), the decoder the
+ *      reference's driver calls (cn/simulator.py:156): list decoding, then the first entry of the sorted list
+ *      that equals the transmitted word (self.message, cn/simulator.py:140-141) is returned, the best entry if
+ *      the list does not hold it.  info_true [B x K] = message[polarMask == 1].  Other arguments as in
+ *      polar_scl_decode.  The reference forks in place (polarSCLFork2, cn/polarCode.py:1041-1097); its
+ *      survivors and sorted list are those of polarSCLFork unless two metrics are exactly equal, where this
+ *      library keeps polarSCLFork's order. */
+int polar_scl_decode_genie(polar_code *code, const void *llr, int dtype, int L, const uint8_t *info_true,
+                           uint8_t *info_hat, double *pm_sorted, uint8_t *u_hat_all, int64_t B, int space);
+int polar_scl_decode_genie_packed(polar_code *code, const void *llr, int dtype, int L, const uint32_t *info_true,
+                                  uint32_t *info_hat, double *pm_sorted, uint32_t *u_hat_all, int64_t B, int space);
+
 /* ---- error counting: pcf.fails per frame (cn/functions.py:107-109) plus the fer/ber counters of the
  *      driver loop (cn/simulator.py:216-226).  Adds to counters[0..2] = frames, frame errors, bit errors
  *      (device uint64[3]).  Packed device buffers.  With POLAR_CRC only the K - width message bits count. */
@@ -136,7 +150,8 @@ int polar_count_errors(polar_code *code, const uint32_t *info_packed, const uint
  *      [frame0, frame0 + nframes).  Nothing but the three counters leaves the GPU.
  *      counters (host uint64[3]) are ADDED to. Frame f always sees the same inputs whatever the chunking
  *      or the number of GPUs, because the generator is keyed by the global frame index.
- *      flags: POLAR_SC_FAST (SC), POLAR_CRC (SCL: CRC-aided frames, selection and counting). */
+ *      flags: POLAR_SC_FAST (SC), POLAR_CRC (SCL: CRC-aided frames, selection and counting),
+ *      POLAR_GENIE (SCL: genie-aided choice against the generated message). */
 int polar_mc_run(polar_code *code, int decoder, int L, int dtype, int flags, double N0, uint64_t seed,
                  uint64_t frame0, int64_t nframes, uint64_t counters[3]);
 

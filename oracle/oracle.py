@@ -49,6 +49,12 @@ def lib():
         L.orc_gen_frame.argtypes = [C.c_uint64, C.c_uint64, _u8p, C.c_int, C.c_int, C.c_double, _u8p, _u8p, _f64p]
         L.orc_mc_run.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                  C.c_uint64, C.c_uint64, C.c_int64, _u64p]
+        for nm in ("orc_scl2_decode_f64", "orc_scl2_decode_f32"):
+            getattr(L, nm).argtypes = [_f64p if nm.endswith("64") else _f32p, _u8p, C.c_int, C.c_int, _u8p, _f64p, _i64p]
+            getattr(L, nm).restype = C.c_int
+        L.orc_genie_select.argtypes = [_u8p, C.c_int, C.c_int, _u8p]
+        L.orc_mc_run_genie.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                       C.c_uint64, C.c_uint64, C.c_int64, _u64p]
         L.orc_crc_encode.argtypes = [_u8p, C.c_int, C.c_uint64, _u8p]
         L.orc_ca_select.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_uint64]
         L.orc_mc_run_crc.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint64,
@@ -187,4 +193,32 @@ def mc_run_crc(mask, L, dtype, N0, crc_poly, seed, frame0, nframes):
     m = _mask(mask)
     c = np.zeros(3, dtype=np.uint64)
     lib().orc_mc_run_crc(m, m.size, int(m.sum()), L, dtype, float(N0), int(crc_poly), seed, frame0, nframes, c)
+    return c
+
+
+def scl2_decode(llr, mask, L):
+    """Single frame through the in-place-fork list decoder (polarSCLFork2).  Same returns as scl_decode."""
+    m = _mask(mask)
+    llr = np.ascontiguousarray(llr)
+    N = m.size
+    uh = np.zeros((L, N), dtype=np.uint8)
+    pm = np.zeros(L, dtype=np.float64)
+    cnt = np.zeros(3, dtype=np.int64)
+    if llr.dtype == np.float32:
+        n = lib().orc_scl2_decode_f32(llr, m, N, L, uh, pm, cnt)
+    else:
+        n = lib().orc_scl2_decode_f64(llr.astype(np.float64, copy=False), m, N, L, uh, pm, cnt)
+    return uh[:n], pm[:n], cnt
+
+
+def genie_select(uhat_sorted, u_true):
+    uh = np.ascontiguousarray(uhat_sorted, dtype=np.uint8)
+    ut = np.ascontiguousarray(u_true, dtype=np.uint8)
+    return lib().orc_genie_select(uh, uh.shape[0], uh.shape[1], ut)
+
+
+def mc_run_genie(mask, L, dtype, N0, seed, frame0, nframes):
+    m = _mask(mask)
+    c = np.zeros(3, dtype=np.uint64)
+    lib().orc_mc_run_genie(m, m.size, int(m.sum()), L, dtype, float(N0), seed, frame0, nframes, c)
     return c

@@ -285,6 +285,106 @@ typedef struct { double pm; int pos; } cand_key;
 DEFINE_SCL(double, f64, branch_metric, PM_KEEP)
 DEFINE_SCL(float, f32, branch_metric_f32, PM_F32)
 
+/* cn/polarCode.py:1267-1317 (sclDecoderOracle, the decoder cn/simulator.py:156 calls) with :1041-1097
+ * (polarSCLFork2).  Same list decoder, but paths stay in their slots: at saturation the 2n candidate metrics
+ * are laid out [u=0 of slot 0..n-1, u=1 of slot 0..n-1] and stable-sorted descending (equal metrics: lower
+ * index first); a slot whose two continuations both survive keeps u=0 and copies itself, with u=1, into the
+ * lowest-numbered slot that lost both (processed in slot order).  The final list is stable-sorted descending
+ * from slot order.  Outputs the whole sorted list; the genie's choice is orc_genie_select on it. */
+#define DEFINE_SCL2(REAL, SUF, BM, PMR)                                                                   \
+    ORC_API int orc_scl2_decode_##SUF(const REAL *llr, const uint8_t *mask, int N, int L,             \
+                                      uint8_t *uhat_all, double *pm_all, int64_t *counts)             \
+    {                                                                                                 \
+        int n = ilog2(N);                                                                             \
+        path_##SUF *list = (path_##SUF *)malloc(sizeof(path_##SUF) * L);                              \
+        for (int j = 0; j < L; j++) path_alloc_##SUF(&list[j], N);                                    \
+        int cur = 1;                                                                                  \
+        int64_t anv = 0, sortnum = 0, unit = 0;                                                       \
+        memcpy(list[0].llr + (N - 1), llr, (size_t)N * sizeof(REAL));                                 \
+        for (int i = 0; i < N; i++) {                                                                 \
+            for (int j = 0; j < cur; j++) { unit += update_llrs_##SUF(&list[j], i, n); anv++; }       \
+            if (mask[i] && 2 * cur <= L) {                                                            \
+                for (int j = 0; j < cur; j++) {                                                       \
+                    path_copy_##SUF(&list[cur + j], &list[j], N);                                     \
+                    double d = list[j].llr[0];                                                        \
+                    list[j].pm = PMR(list[j].pm + BM(d, 0));                                          \
+                    list[cur + j].uhat[i] = 1;                                                        \
+                    list[cur + j].pm = PMR(list[cur + j].pm + BM(d, 1));                              \
+                }                                                                                     \
+                cur *= 2;                                                                             \
+            } else if (mask[i]) {                                                                     \
+                double PM[128];                                                                       \
+                int order[128], discard[128], state[64], lost[64], nlost = 0, next_lost = 0;          \
+                for (int j = 0; j < cur; j++) {                                                       \
+                    double d = list[j].llr[0];                                                        \
+                    PM[j] = PMR(list[j].pm + BM(d, 0));                                               \
+                    PM[j + cur] = PMR(list[j].pm + BM(d, 1));                                         \
+                }                                                                                     \
+                sortnum++;                                                                            \
+                for (int c = 0; c < 2 * cur; c++) { order[c] = c; discard[c] = 1; }                   \
+                for (int a = 1; a < 2 * cur; a++) {                                                   \
+                    int v = order[a], b = a - 1;                                                      \
+                    while (b >= 0 && PM[order[b]] < PM[v]) { order[b + 1] = order[b]; b--; }          \
+                    order[b + 1] = v;                                                                 \
+                }                                                                                     \
+                for (int c = 0; c < L; c++) discard[order[c]] = 0;                                    \
+                for (int j = 0; j < cur; j++) {                                                       \
+                    if (discard[j] && discard[j + cur]) { state[j] = 1; lost[nlost++] = j; }          \
+                    else if (discard[j]) state[j] = 2;                                                \
+                    else if (discard[j + cur]) state[j] = 3;                                          \
+                    else state[j] = 4;                                                                \
+                }                                                                                     \
+                for (int j = 0; j < cur; j++) {                                                       \
+                    if (state[j] == 2) { list[j].pm = PM[j + cur]; list[j].uhat[i] = 1; }             \
+                    else if (state[j] == 3) { list[j].pm = PM[j]; }                                   \
+                    else if (state[j] == 4) {                                                         \
+                        int t = lost[next_lost++];                                                    \
+                        path_copy_##SUF(&list[t], &list[j], N);                                       \
+                        list[j].pm = PM[j];                                                           \
+                        list[t].pm = PM[j + cur];                                                     \
+                        list[t].uhat[i] = 1;                                                          \
+                    }                                                                                 \
+                }                                                                                     \
+            } else {                                                                                  \
+                for (int j = 0; j < cur; j++) {                                                       \
+                    list[j].uhat[i] = 0;                                                              \
+                    list[j].pm = PMR(list[j].pm + BM(list[j].llr[0], 0));                             \
+                }                                                                                     \
+            }                                                                                         \
+            for (int j = 0; j < cur; j++) update_bits_##SUF(&list[j], i, N);                          \
+        }                                                                                             \
+        {                                                                                             \
+            int order[128];                                                                           \
+            for (int c = 0; c < cur; c++) order[c] = c;                                               \
+            for (int a = 1; a < cur; a++) {                                                           \
+                int v = order[a], b = a - 1;                                                          \
+                while (b >= 0 && list[order[b]].pm < list[v].pm) { order[b + 1] = order[b]; b--; }    \
+                order[b + 1] = v;                                                                     \
+            }                                                                                         \
+            sortnum++;                                                                                \
+            for (int c = 0; c < cur; c++) {                                                           \
+                memcpy(uhat_all + (size_t)c * N, list[order[c]].uhat, N);                             \
+                pm_all[c] = list[order[c]].pm;                                                        \
+            }                                                                                         \
+        }                                                                                             \
+        if (counts) { counts[0] = anv; counts[1] = sortnum; counts[2] = unit; }                       \
+        for (int j = 0; j < L; j++) path_free_##SUF(&list[j]);                                        \
+        free(list);                                                                                   \
+        return cur;                                                                                   \
+    }
+
+DEFINE_SCL2(double, f64, branch_metric, PM_KEEP)
+DEFINE_SCL2(float, f32, branch_metric_f32, PM_F32)
+
+/* The genie of sclDecoderOracle (cn/polarCode.py:1314-1317): the first entry of the sorted list equal to the
+ * transmitted u (self.message), the best entry if there is none.  Returns the row. */
+ORC_API int orc_genie_select(const uint8_t *uhat_sorted, int nsurv, int N, const uint8_t *u_true)
+{
+    for (int j = 0; j < nsurv; j++)
+        if (memcmp(uhat_sorted + (size_t)j * N, u_true, (size_t)N) == 0) return j;
+    return 0;
+}
+
 /* ------------------------------------------------------------------ batched wrappers (cpu_baseline, tests) */
 ORC_API void orc_sc_decode_batch_f32(const float *llr, const uint8_t *mask, int N, int64_t B, uint8_t *uhat)
 {
@@ -481,4 +581,31 @@ ORC_API void orc_mc_run_crc(const uint8_t *mask, int N, int K, int L, int dtype,
         counters[2] += (uint64_t)e;
     }
     free(info); free(msg); free(x); free(uh); free(dec); free(llr); free(pm); free(z); free(llrf);
+}
+
+/* Genie-aided Monte-Carlo loop: orc_mc_run with sclDecoderOracle in place of sclDecoder (cn/simulator.py:156). */
+ORC_API void orc_mc_run_genie(const uint8_t *mask, int N, int K, int L, int dtype, double N0,
+                              uint64_t seed, uint64_t frame0, int64_t nframes, uint64_t counters[3])
+{
+    uint8_t *info = malloc(K), *x = malloc(N), *uh = malloc((size_t)N * L), *dec = malloc(K), *ut = malloc(N);
+    double *llr = malloc(sizeof(double) * N), *pm = malloc(sizeof(double) * L);
+    float *llrf = malloc(sizeof(float) * N);
+    for (int64_t f = 0; f < nframes; f++) {
+        orc_gen_frame(seed, frame0 + f, mask, N, K, N0, info, x, llr);
+        int nsurv;
+        if (dtype == 0) {
+            for (int i = 0; i < N; i++) llrf[i] = (float)llr[i];
+            nsurv = orc_scl2_decode_f32(llrf, mask, N, L, uh, pm, NULL);
+        } else {
+            nsurv = orc_scl2_decode_f64(llr, mask, N, L, uh, pm, NULL);
+        }
+        for (int i = 0, k = 0; i < N; i++) ut[i] = mask[i] ? info[k++] : 0;
+        int j = orc_genie_select(uh, nsurv, N, ut);
+        orc_extract(uh + (size_t)j * N, mask, N, dec);
+        int64_t e = orc_fails(info, dec, K);
+        counters[0] += 1;
+        counters[1] += (e > 0);
+        counters[2] += (uint64_t)e;
+    }
+    free(info); free(x); free(uh); free(dec); free(ut); free(llr); free(pm); free(llrf);
 }

@@ -15,6 +15,7 @@ F32, F64 = 0, 1
 DEC_SC, DEC_SCL = 0, 1
 SC_FAST = 1
 CRC = 2
+GENIE = 4
 
 _lib = None
 _default_ctx = None
@@ -57,6 +58,8 @@ SIGNATURES = {
     "polar_sc_decode_packed": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _i]),
     "polar_scl_decode": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _i64, _i, _i]),
     "polar_scl_decode_packed": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _i64, _i, _i]),
+    "polar_scl_decode_genie": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _i]),
+    "polar_scl_decode_genie_packed": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _i]),
     "polar_count_errors": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "polar_mc_run": (_i, [_vp, _i, _i, _i, _i, _d, _u64, _u64, _i64, _vp]),
     "polar_last_launch": (_i, [_vp, C.POINTER(LaunchInfo)]),
@@ -222,9 +225,24 @@ class Code:
                                       CRC if crc else 0, HOST))
         return info, pm, uh
 
-    def mc_run(self, decoder, L, dtype, N0, seed, frame0, nframes, fast=True, crc=False):
+    def scl_decode_genie(self, llr, L, info_true, want_list=False):
+        """List decoding with the genie's choice: the list entry equal to info_true [B, K] if there is one."""
+        llr = np.ascontiguousarray(np.atleast_2d(llr))
+        if llr.dtype not in (np.float32, np.float64):
+            llr = llr.astype(np.float64)
+        B = llr.shape[0]
+        truth = np.ascontiguousarray(np.atleast_2d(info_true), dtype=np.uint8)
+        assert llr.shape[1] == self.N and truth.shape == (B, self.K)
+        info = np.empty((B, self.K), dtype=np.uint8)
+        pm = np.empty((B, L), dtype=np.float64) if want_list else None
+        uh = np.empty((B, L, self.N), dtype=np.uint8) if want_list else None
+        _check(lib().polar_scl_decode_genie(self._h, llr.ctypes.data, _dt(llr.dtype), L, truth.ctypes.data, info.ctypes.data,
+                                            _ptr(pm), _ptr(uh), B, HOST))
+        return info, pm, uh
+
+    def mc_run(self, decoder, L, dtype, N0, seed, frame0, nframes, fast=True, crc=False, genie=False):
         cnt = np.zeros(3, dtype=np.uint64)
-        flags = (SC_FAST if (fast and decoder == DEC_SC) else 0) | (CRC if crc else 0)
+        flags = (SC_FAST if (fast and decoder == DEC_SC) else 0) | (CRC if crc else 0) | (GENIE if genie else 0)
         _check(lib().polar_mc_run(self._h, decoder, L, _dt(dtype), flags, float(N0),
                                   seed, frame0, nframes, cnt.ctypes.data))
         return cnt
@@ -240,6 +258,10 @@ class Code:
     def scl_decode_dev(self, llr_ptr, dtype, L, info_hat_ptr, B, pm_ptr=None, u_hat_ptr=None, crc=False):
         _check(lib().polar_scl_decode_packed(self._h, llr_ptr, _dt(dtype), L, info_hat_ptr, pm_ptr, u_hat_ptr, B,
                                              CRC if crc else 0, DEVICE))
+
+    def scl_decode_genie_dev(self, llr_ptr, dtype, L, info_true_ptr, info_hat_ptr, B, pm_ptr=None, u_hat_ptr=None):
+        _check(lib().polar_scl_decode_genie_packed(self._h, llr_ptr, _dt(dtype), L, info_true_ptr, info_hat_ptr, pm_ptr,
+                                                   u_hat_ptr, B, DEVICE))
 
     def count_errors_dev(self, info_ptr, hat_ptr, B, counters_ptr, crc=False):
         _check(lib().polar_count_errors(self._h, info_ptr, hat_ptr, B, CRC if crc else 0, counters_ptr))

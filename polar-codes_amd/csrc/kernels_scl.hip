@@ -27,6 +27,7 @@ template <typename T> struct SCLParams {
     const uint32_t *ops;
     const uint32_t *A;
     const uint32_t *crcS;  // per information bit: its contribution to the CRC remainder; NULL = take the best path
+    const uint32_t *truth; // [B x Kw] transmitted information words; non-NULL = take the list entry equal to them
     uint32_t *info_hat;
     double *pm;
     uint32_t *u_hat_all;
@@ -277,17 +278,34 @@ __global__ void __launch_bounds__(64) scl_decode_kernel(SCLParams<T> p, const ui
             // every group packs its own bits (the ballots are wave-wide); only the best path stores
             uint32_t *dst = p.info_hat + f * p.Kw;
             int sel = 0;
-            if (p.crcS) {
-                // CRC-aided choice: first path in sorted order whose information word leaves a zero remainder
-                uint32_t syn = 0;
-                for (int k = sub; k < p.K; k += G) {
-                    uint32_t pos = p.A[k];
-                    if ((uw[pos >> 5] >> (pos & 31)) & 1u) syn ^= p.crcS[k];
+            if (p.crcS || p.truth) {
+                // aided choice: the first path in sorted order that passes, the best one if none does
+                bool ok;
+                if (p.truth) {
+                    // genie: the path's information word equals the transmitted one
+                    const uint32_t *tw = p.truth + f * p.Kw;
+                    bool differs = false;
+                    pack_bits_group<G>(
+                        p.K, sub, grp,
+                        [&](int k) {
+                            uint32_t pos = p.A[k];
+                            return ((uw[pos >> 5] >> (pos & 31)) & 1u) != 0u;
+                        },
+                        [&](int wi, uint32_t v) { differs |= (v != tw[wi]); });
+                    ok = !differs;
+                } else {
+                    // CRC: the information word leaves a zero remainder
+                    uint32_t syn = 0;
+                    for (int k = sub; k < p.K; k += G) {
+                        uint32_t pos = p.A[k];
+                        if ((uw[pos >> 5] >> (pos & 31)) & 1u) syn ^= p.crcS[k];
+                    }
+                    for (int off = 1; off < G; off <<= 1) syn ^= shfl_u32(syn, lane ^ off);
+                    ok = syn == 0u;
                 }
-                for (int off = 1; off < G; off <<= 1) syn ^= shfl_u32(syn, lane ^ off);
                 if (lane == 0) surv[0] = 0u;
                 wave_sync();
-                if (sub == 0 && act && syn == 0u) atomicOr(&surv[0], 1u << rank);
+                if (sub == 0 && act && ok) atomicOr(&surv[0], 1u << rank);
                 wave_sync();
                 const uint32_t pass = surv[0];
                 sel = pass ? __ffs(pass) - 1 : 0;
@@ -310,7 +328,8 @@ __global__ void __launch_bounds__(64) scl_decode_kernel(SCLParams<T> p, const ui
 
 // ------------------------------------------------------------------------------------------ launch
 template <typename T, int L>
-static int launch_scl_t(polar_code *c, const void *llr, uint32_t *info_hat, double *pm, uint32_t *u_hat_all, int64_t B, bool crc)
+static int launch_scl_t(polar_code *c, const void *llr, uint32_t *info_hat, double *pm, uint32_t *u_hat_all, int64_t B, bool crc,
+                       const uint32_t *truth)
 {
     polar_ctx *ctx = c->ctx;
     constexpr int G = 64 / L;
@@ -319,6 +338,7 @@ static int launch_scl_t(polar_code *c, const void *llr, uint32_t *info_hat, doub
     p.ops = c->d_sched[0];
     p.A = c->d_A;
     p.crcS = crc ? c->d_crcS : nullptr;
+    p.truth = truth;
     p.info_hat = info_hat;
     p.pm = pm;
     p.u_hat_all = u_hat_all;
@@ -358,28 +378,28 @@ static int launch_scl_t(polar_code *c, const void *llr, uint32_t *info_hat, doub
 
 template <typename T>
 static int launch_scl_l(polar_code *c, const void *llr, int L, uint32_t *info_hat, double *pm, uint32_t *u_hat_all, int64_t B,
-                       bool crc)
+                       bool crc, const uint32_t *truth)
 {
     switch (L) {
-    case 1: return launch_scl_t<T, 1>(c, llr, info_hat, pm, u_hat_all, B, crc);
-    case 2: return launch_scl_t<T, 2>(c, llr, info_hat, pm, u_hat_all, B, crc);
-    case 4: return launch_scl_t<T, 4>(c, llr, info_hat, pm, u_hat_all, B, crc);
-    case 8: return launch_scl_t<T, 8>(c, llr, info_hat, pm, u_hat_all, B, crc);
-    case 16: return launch_scl_t<T, 16>(c, llr, info_hat, pm, u_hat_all, B, crc);
-    case 32: return launch_scl_t<T, 32>(c, llr, info_hat, pm, u_hat_all, B, crc);
+    case 1: return launch_scl_t<T, 1>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
+    case 2: return launch_scl_t<T, 2>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
+    case 4: return launch_scl_t<T, 4>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
+    case 8: return launch_scl_t<T, 8>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
+    case 16: return launch_scl_t<T, 16>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
+    case 32: return launch_scl_t<T, 32>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
     default: polar_set_error("SCL decoder: unsupported list size %d", L); return POLAR_EINVAL;
     }
 }
 
 int launch_scl_decode(polar_code *c, const void *llr, int dtype, int L, uint32_t *info_hat, double *pm, uint32_t *u_hat_all,
-                      int64_t B, bool crc)
+                      int64_t B, bool crc, const uint32_t *truth)
 {
     if (B == 0) return POLAR_OK;
     if (c->n > 12) {
         polar_set_error("SCL decoder: N=%d exceeds the supported maximum of 4096", c->N);
         return POLAR_EUNSUPPORTED;
     }
-    if (scl_reg_supported(c, dtype, L, pm, u_hat_all)) return launch_scl_reg(c, llr, info_hat, B, crc);
-    if (dtype == POLAR_F32) return launch_scl_l<float>(c, llr, L, info_hat, pm, u_hat_all, B, crc);
-    return launch_scl_l<double>(c, llr, L, info_hat, pm, u_hat_all, B, crc);
+    if (scl_reg_supported(c, dtype, L, pm, u_hat_all)) return launch_scl_reg(c, llr, info_hat, B, crc, truth);
+    if (dtype == POLAR_F32) return launch_scl_l<float>(c, llr, L, info_hat, pm, u_hat_all, B, crc, truth);
+    return launch_scl_l<double>(c, llr, L, info_hat, pm, u_hat_all, B, crc, truth);
 }

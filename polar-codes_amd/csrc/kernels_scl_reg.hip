@@ -286,7 +286,8 @@ __device__ __forceinline__ void scl_node(SclReg<NLOG> &d, uint32_t maskv, const 
 template <int NLOG>
 __global__ void __launch_bounds__(64, 2) scl_reg_kernel(const float *__restrict__ llr, const uint32_t *__restrict__ maskw,
                                                         const uint32_t *__restrict__ Asl8, const uint32_t *__restrict__ crcS,
-                                                        uint32_t *__restrict__ info_hat, int64_t B, int K, int Kw)
+                                                        const uint32_t *__restrict__ truth, uint32_t *__restrict__ info_hat, int64_t B,
+                                                        int K, int Kw)
 {
     __shared__ uint32_t surv[8];
     __shared__ uint32_t stage[64 * 4];  // 8 paths x 8 lanes x 128-bit slice of u_hat
@@ -367,11 +368,22 @@ __global__ void __launch_bounds__(64, 2) scl_reg_kernel(const float *__restrict_
                     }
                 });
             int sel = 0;
-            if (crcS) {
-                // CRC-aided choice: first path in sorted order whose information word leaves a zero remainder
-                syn ^= partner8_u<2>(syn);
-                syn ^= partner8_u<4>(syn);
-                syn ^= partner8_u<8>(syn);
+            if (crcS || truth) {
+                // aided choice: the first path in sorted order that passes, the best one if none does.
+                // CRC: the information word leaves a zero remainder; genie: it equals the transmitted word
+                if (truth) {
+                    syn = 0u;
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if (lc.q + 8 * i < Kw) syn |= wout[i] ^ truth[f * Kw + lc.q + 8 * i];
+                    syn |= partner8_u<2>(syn);
+                    syn |= partner8_u<4>(syn);
+                    syn |= partner8_u<8>(syn);
+                } else {
+                    syn ^= partner8_u<2>(syn);
+                    syn ^= partner8_u<4>(syn);
+                    syn ^= partner8_u<8>(syn);
+                }
                 if (lc.lane == 0) surv[0] = 0u;
                 wave_sync();
                 if (lc.q == 0 && act && syn == 0u) atomicOr(&surv[0], 1u << rank);
@@ -401,7 +413,8 @@ bool scl_reg_supported(const polar_code *c, int dtype, int L, const void *pm, co
     return true;
 }
 
-template <int NLOG> static int launch_scl_reg_t(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, bool crc)
+template <int NLOG>
+static int launch_scl_reg_t(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, bool crc, const uint32_t *truth)
 {
     polar_ctx *ctx = c->ctx;
     auto kern = scl_reg_kernel<NLOG>;
@@ -411,7 +424,7 @@ template <int NLOG> static int launch_scl_reg_t(polar_code *c, const void *llr, 
     int64_t grid = std::min<int64_t>(B, (int64_t)ctx->num_cus * occ * 8);
     LaunchTimer tm(ctx);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), 0, ctx->stream, (const float *)llr, (const uint32_t *)c->d_maskw,
-                       (const uint32_t *)c->d_Asl8, crc ? (const uint32_t *)c->d_crcS : nullptr, info_hat, B, c->K, c->Kw);
+                       (const uint32_t *)c->d_Asl8, crc ? (const uint32_t *)c->d_crcS : nullptr, truth, info_hat, B, c->K, c->Kw);
     HIP_TRY(hipGetLastError());
     float ms = tm.stop();
     snprintf(c->last.kernel, sizeof(c->last.kernel), "scl_reg_kernel<%d>/L8", NLOG);
@@ -423,15 +436,15 @@ template <int NLOG> static int launch_scl_reg_t(polar_code *c, const void *llr, 
     return POLAR_OK;
 }
 
-int launch_scl_reg(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, bool crc)
+int launch_scl_reg(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, bool crc, const uint32_t *truth)
 {
     if (B == 0) return POLAR_OK;
     switch (c->n) {
-    case 6: return launch_scl_reg_t<6>(c, llr, info_hat, B, crc);
-    case 7: return launch_scl_reg_t<7>(c, llr, info_hat, B, crc);
-    case 8: return launch_scl_reg_t<8>(c, llr, info_hat, B, crc);
-    case 9: return launch_scl_reg_t<9>(c, llr, info_hat, B, crc);
-    case 10: return launch_scl_reg_t<10>(c, llr, info_hat, B, crc);
+    case 6: return launch_scl_reg_t<6>(c, llr, info_hat, B, crc, truth);
+    case 7: return launch_scl_reg_t<7>(c, llr, info_hat, B, crc, truth);
+    case 8: return launch_scl_reg_t<8>(c, llr, info_hat, B, crc, truth);
+    case 9: return launch_scl_reg_t<9>(c, llr, info_hat, B, crc, truth);
+    case 10: return launch_scl_reg_t<10>(c, llr, info_hat, B, crc, truth);
     default: polar_set_error("register SCL kernel: unsupported length"); return POLAR_EUNSUPPORTED;
     }
 }

@@ -461,7 +461,7 @@ extern "C" int polar_sc_decode_packed(polar_code *c, const void *llr, int dtype,
 
 // ---------------------------------------------------------------------------------------------- SCL
 static int scl_common(polar_code *c, const void *llr, int dtype, int L, void *info_hat, double *pm,
-                      void *u_hat_all, int64_t B, int flags, int space, bool packed)
+                      void *u_hat_all, int64_t B, int flags, int space, bool packed, const void *truth = nullptr)
 {
     CHECK_COMMON(c, B, space);
     CRC_TRY(c, flags);
@@ -472,7 +472,7 @@ static int scl_common(polar_code *c, const void *llr, int dtype, int L, void *in
     polar_ctx *ctx = c->ctx;
     const size_t es = llr_size(dtype);
     if (space == POLAR_DEVICE && packed)
-        return launch_scl_decode(c, llr, dtype, L, (uint32_t *)info_hat, pm, (uint32_t *)u_hat_all, B, crc);
+        return launch_scl_decode(c, llr, dtype, L, (uint32_t *)info_hat, pm, (uint32_t *)u_hat_all, B, crc, (const uint32_t *)truth);
     int rc;
     const int64_t chunk = (space == POLAR_HOST) ? std::max<int64_t>(1, HOST_CHUNK / L) : (int64_t)1 << 18;
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
@@ -488,7 +488,27 @@ static int scl_common(polar_code *c, const void *llr, int dtype, int L, void *in
             HIP_TRY(hipMemcpyAsync(ctx->llr_buf.p, dl, nb * c->N * es, hipMemcpyHostToDevice, ctx->stream));
             dl = ctx->llr_buf.as<char>();
         }
-        if ((rc = launch_scl_decode(c, dl, dtype, L, wi, dpm, wu, nb, crc))) return rc;
+        const uint32_t *wt = nullptr;
+        if (truth) {
+            if (packed && space == POLAR_DEVICE) {
+                wt = (const uint32_t *)truth + b0 * c->Kw;
+            } else {
+                if ((rc = ctx->in_words.reserve(nb * c->Kw * 4))) return rc;
+                wt = ctx->in_words.as<uint32_t>();
+                if (packed) {  // host words
+                    HIP_TRY(hipMemcpyAsync(ctx->in_words.p, (const uint32_t *)truth + b0 * c->Kw, nb * c->Kw * 4, hipMemcpyHostToDevice, ctx->stream));
+                } else {
+                    const uint8_t *tb = (const uint8_t *)truth + b0 * c->K;
+                    if (space == POLAR_HOST) {
+                        if ((rc = ctx->in_bytes.reserve(std::max<size_t>(1, nb * c->K)))) return rc;
+                        if (c->K) HIP_TRY(hipMemcpyAsync(ctx->in_bytes.p, tb, nb * c->K, hipMemcpyHostToDevice, ctx->stream));
+                        tb = ctx->in_bytes.as<uint8_t>();
+                    }
+                    if ((rc = launch_pack_bits(ctx, tb, ctx->in_words.as<uint32_t>(), nb, c->K))) return rc;
+                }
+            }
+        }
+        if ((rc = launch_scl_decode(c, dl, dtype, L, wi, dpm, wu, nb, crc, wt))) return rc;
         if (packed) {
             if (info_hat) HIP_TRY(hipMemcpyAsync((uint32_t *)info_hat + b0 * c->Kw, wi, nb * c->Kw * 4, hipMemcpyDeviceToHost, ctx->stream));
             if (u_hat_all) HIP_TRY(hipMemcpyAsync((uint32_t *)u_hat_all + b0 * L * c->Nw, wu, nb * L * c->Nw * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -530,6 +550,19 @@ extern "C" int polar_scl_decode_packed(polar_code *c, const void *llr, int dtype
     return scl_common(c, llr, dtype, L, info_hat, pm, u_hat_all, B, flags, space, true);
 }
 
+extern "C" int polar_scl_decode_genie(polar_code *c, const void *llr, int dtype, int L, const uint8_t *info_true,
+                                      uint8_t *info_hat, double *pm, uint8_t *u_hat_all, int64_t B, int space)
+{
+    ARG_TRY(info_true != nullptr, "info_true is NULL");
+    return scl_common(c, llr, dtype, L, info_hat, pm, u_hat_all, B, 0, space, false, info_true);
+}
+extern "C" int polar_scl_decode_genie_packed(polar_code *c, const void *llr, int dtype, int L, const uint32_t *info_true,
+                                             uint32_t *info_hat, double *pm, uint32_t *u_hat_all, int64_t B, int space)
+{
+    ARG_TRY(info_true != nullptr, "info_true is NULL");
+    return scl_common(c, llr, dtype, L, info_hat, pm, u_hat_all, B, 0, space, true, info_true);
+}
+
 // ---------------------------------------------------------------------------------------------- counting / MC
 extern "C" int polar_count_errors(polar_code *c, const uint32_t *info, const uint32_t *hat, int64_t B, int flags,
                                   uint64_t *counters)
@@ -552,6 +585,8 @@ extern "C" int polar_mc_run(polar_code *c, int decoder, int L, int dtype, int fl
         ARG_TRY(L == 1 || L == 2 || L == 4 || L == 8 || L == 16 || L == 32, "L must be a power of two in [1, 32]");
     CRC_TRY(c, flags);
     ARG_TRY(!((flags & POLAR_CRC) && decoder != POLAR_DEC_SCL), "POLAR_CRC goes with the list decoder");
+    ARG_TRY(!((flags & POLAR_GENIE) && decoder != POLAR_DEC_SCL), "POLAR_GENIE goes with the list decoder");
+    ARG_TRY(!((flags & POLAR_GENIE) && (flags & POLAR_CRC)), "POLAR_GENIE and POLAR_CRC exclude each other");
     const bool crc = (flags & POLAR_CRC) != 0;
     polar_ctx *ctx = c->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -572,7 +607,8 @@ extern "C" int polar_mc_run(polar_code *c, int decoder, int L, int dtype, int fl
         if (decoder == POLAR_DEC_SC)
             rc = launch_sc_decode(c, ctx->llr_buf.p, dtype, ctx->mc_hat.as<uint32_t>(), nullptr, nullptr, nb, flags);
         else
-            rc = launch_scl_decode(c, ctx->llr_buf.p, dtype, L, ctx->mc_hat.as<uint32_t>(), nullptr, nullptr, nb, crc);
+            rc = launch_scl_decode(c, ctx->llr_buf.p, dtype, L, ctx->mc_hat.as<uint32_t>(), nullptr, nullptr, nb, crc,
+                                   (flags & POLAR_GENIE) ? ctx->mc_info.as<uint32_t>() : nullptr);
         if (rc) return rc;
         if ((rc = launch_count_errors(c, ctx->mc_info.as<uint32_t>(), ctx->mc_hat.as<uint32_t>(), nb, dcnt,
                                       crc ? c->K - c->crc_w : c->K)))

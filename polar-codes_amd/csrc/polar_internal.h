@@ -107,9 +107,10 @@ int launch_sc_decode(polar_code *c, const void *llr, int dtype, uint32_t *info_h
 bool sc_reg_supported(const polar_code *c, int dtype, const void *u_hat, const void *dec_llr);
 int launch_sc_reg(polar_code *c, const void *llr, int dtype, uint32_t *info_hat, int64_t B, int flags);
 bool scl_reg_supported(const polar_code *c, int dtype, int L, const void *pm, const void *u_hat_all);
-int launch_scl_reg(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, bool crc);
+// truth (packed [B x Kw], or NULL): genie-aided choice of the output path
+int launch_scl_reg(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, bool crc, const uint32_t *truth);
 int launch_scl_decode(polar_code *c, const void *llr, int dtype, int L, uint32_t *info_hat, double *pm,
-                      uint32_t *u_hat_all, int64_t B, bool crc);
+                      uint32_t *u_hat_all, int64_t B, bool crc, const uint32_t *truth);
 // nbits: leading bits of each K-bit word that are compared
 int launch_count_errors(polar_code *c, const uint32_t *info, const uint32_t *hat, int64_t B, uint64_t *counters, int nbits);
 

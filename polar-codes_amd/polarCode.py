@@ -182,7 +182,14 @@ class PolarCode:
         self.predictIdx = []
         return info.reshape(batch + (self.infoLen,)).astype(int)
 
-    def sclDecoder(self, softMess, isCRC=False, isRCPP=False):
+    def sclDecoderOracle(self, softMess, isCRC=False, isRCPP=False):
+        """Genie-aided list decoding (cn/polarCode.py:1267-1317), the decoder the reference's driver calls
+        (cn/simulator.py:156): sclDecoder's list, then the first entry equal to self.message (the transmitted
+        u, set by the caller as in cn/simulator.py:140-141; [N] or [B, N]) is returned, the best one if the list
+        does not hold it.  isCRC is accepted and ignored like in the reference."""
+        return self.sclDecoder(softMess, isRCPP=isRCPP, _genie=True)
+
+    def sclDecoder(self, softMess, isCRC=False, isRCPP=False, _genie=False):
         """List decoding with list size self.L (cn/polarCode.py:2032-2102, 969-1005).  Sets self.pathList
         (survivors sorted by metric, descending, ties in the reference's stable order), self.ANV,
         self.sortNum, self.unitCal; returns the information bits of the best path."""
@@ -194,7 +201,16 @@ class PolarCode:
         crc_dev = bool(isCRC) and not self.bitReversed
         if crc_dev:
             self._attach_crc()
-        info, pm, uh = self._active.scl_decode(llr.reshape(-1, self.codewordLength), L, want_list=True, crc=crc_dev)
+        if _genie:
+            msg = np.broadcast_to(np.asarray(self.message), batch + (self.codewordLength,)).reshape(-1, self.codewordLength)
+            truth = msg[:, self.polarMask == 1]
+            # a "message" with ones on frozen positions can never equal a decoded word
+            possible = ~(msg[:, self.polarMask == 0] != 0).any(axis=1)
+        if _genie and not self.bitReversed:
+            info, pm, uh = self._active.scl_decode_genie(llr.reshape(-1, self.codewordLength), L, truth, want_list=True)
+            info = np.where(possible[:, None], info, uh[:, 0][:, self.polarMask == 1])
+        else:
+            info, pm, uh = self._active.scl_decode(llr.reshape(-1, self.codewordLength), L, want_list=True, crc=crc_dev)
         if self.bitReversed:
             uh = uh[:, :, self._rev]
             info = uh[:, 0][:, self.polarMask == 1]
@@ -205,6 +221,13 @@ class PolarCode:
             self.pathList = [[Path(uh[b, j].astype(int), pm[b, j]) for j in range(nsurv)] for b in range(uh.shape[0])]
         self.pathMetrics = pm.reshape(batch + (L,))
         self.ANV, self.sortNum, self.unitCal = self._scl_counts(L)
+        if _genie and self.bitReversed:
+            # bit-reversed ordering: the genie's choice made here from the list the GPU returned
+            words = uh[:, :, self.polarMask == 1]
+            hit = (words == truth[:, None, :]).all(axis=2) & possible[:, None]
+            hit[:, nsurv:] = False
+            pick = np.where(hit.any(axis=1), hit.argmax(axis=1), 0)
+            info = words[np.arange(words.shape[0]), pick]
         if crc_dev:
             # the GPU picked the first survivor, in list order, whose information word passes the CRC, else the
             # best one; the CRC bits are dropped from the result (cn/polarCode.py:2079-2097)

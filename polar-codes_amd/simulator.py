@@ -66,7 +66,7 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def native_runner(pcode, decoder, L, dtype, crc=False):
+def native_runner(pcode, decoder, L, dtype, crc=False, genie=False):
     """Default frame runner: polar_mc_run of the GPU library."""
     import _native
 
@@ -75,14 +75,14 @@ def native_runner(pcode, decoder, L, dtype, crc=False):
         pcode._attach_crc()
 
     def run(N0, seed, frame0, nframes):
-        return pcode.native.mc_run(dec, L, dtype, N0, seed, frame0, nframes, crc=crc)
+        return pcode.native.mc_run(dec, L, dtype, N0, seed, frame0, nframes, crc=crc, genie=genie)
 
     return run
 
 
 def simulate(pcode, snrRange, frames=None, errCnt=100, minFrames=100000, maxFrames=10 ** 8, seed=2024, decoder=None,
              L=None, dtype=np.float32, batch=1 << 18, snrType=None, modu=None, verbose=True, dist=None, runner=None,
-             reduce_device=None, isCRC=None):
+             reduce_device=None, isCRC=None, genie=False):
     """Eb/N0 (or Es/N0) sweep.
 
     frames=int   -> exactly that many frames per SNR point (split evenly over the ranks);
@@ -93,10 +93,14 @@ def simulate(pcode, snrRange, frames=None, errCnt=100, minFrames=100000, maxFram
     (cn/simulator.py:78-83).  isCRC (default pcode.isCRC) runs CRC-aided list decoding: pcode.infoLen then
     counts the CRC bits (the reference's K2 = K + crcWidth, cn/simulator.py:22,75), the message has
     infoLen - crcWidth bits, and rate and BER refer to the message (cn/simulator.py:20,133,360).
+    genie=True (or decoder='scl-oracle') decodes with sclDecoderOracle, the call the reference's loop actually
+    makes (cn/simulator.py:156): the transmitted word is returned whenever the final list holds it.
     Returns a BERFER; every rank returns the same totals.
     """
     rank, world, dist = _dist_state(dist)
     decoder = (decoder or getattr(pcode, "decoderType", "sc") or "sc").lower()
+    if decoder in ("scl-oracle", "scloracle", "genie"):
+        decoder, genie = "scl", True
     if decoder not in ("sc", "scl"):
         raise NotImplementedError("decoder %r is not provided" % (decoder,))
     L = int(L if L is not None else (getattr(pcode, "L", 0) or 1))
@@ -107,7 +111,9 @@ def simulate(pcode, snrRange, frames=None, errCnt=100, minFrames=100000, maxFram
         raise ValueError("isCRC needs the list decoder")
     msgLen = pcode.infoLen - (pcode.crcWidth if isCRC else 0)
     rate = msgLen / pcode.codewordLength
-    run = runner or native_runner(pcode, decoder, L, dtype, crc=isCRC)
+    if genie and (decoder != "scl" or isCRC):
+        raise ValueError("the genie goes with the plain list decoder")
+    run = runner or native_runner(pcode, decoder, L, dtype, crc=isCRC, genie=genie)
     if reduce_device is None:
         reduce_device = "cpu"
         if dist is not None and dist.get_backend() == "nccl":
@@ -165,7 +171,7 @@ def main(argv=None):
     ap.add_argument("--K", type=int, default=512)
     ap.add_argument("--construct", default="dega")
     ap.add_argument("--dsnr", type=float, default=2.0)
-    ap.add_argument("--decoder", default="sc", choices=["sc", "scl"])
+    ap.add_argument("--decoder", default="sc", choices=["sc", "scl", "scl-oracle"])
     ap.add_argument("--L", type=int, default=8)
     ap.add_argument("--snr", type=float, nargs="+", default=[1.0, 1.5, 2.0, 2.5, 3.0])
     ap.add_argument("--frames", type=int, default=None)

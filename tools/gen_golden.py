@@ -394,7 +394,53 @@ def gen_cascl(functions, polarCode, channel):
     np.savez_compressed(os.path.join(OUT, "cascl.npz"), **out)
 
 
-SECTIONS = {"masks": gen_masks, "encoder": gen_encoder, "channel": gen_channel, "sc": gen_sc, "scl": gen_scl, "curves": gen_curves, "mainflow": gen_mainflow, "cascl": gen_cascl}
+# --------------------------------------------------------------------------- N3: sclDecoderOracle / polarSCLFork2
+def gen_genie(functions, polarCode, channel):
+    """Frames decoded by sclDecoderOracle (cn/polarCode.py:1267-1317), the call cn/simulator.py:156 makes:
+    list decoding with the in-place fork polarSCLFork2 and the genie's choice (pcode.message)."""
+    out = {}
+    cfgs = [(128, 64, "dega", 2, 0.0, 120), (128, 64, "dega", 4, 0.0, 120), (128, 64, "dega", 8, 1.0, 60),
+            (256, 128, "dega", 16, 0.5, 30), (1024, 512, "dega", 8, 1.0, 40), (512, 256, "rmpolar", 32, 1.5, 10)]
+    for (N, K, cons, L, snr, nfr) in cfgs:
+        pc = make_code(polarCode, functions, N, K, cons, 2.0)
+        pc.L = L
+        ch = channel.Channel("BPSK", snr, "SNRb", K / N)
+        tag = f"{cons}_{N}_{K}_L{L}_{snr}"
+        seeds, decs, pml, uhl, nerr, where, plain, cnts = [], [], [], [], [], [], [], []
+        t0 = time.time()
+        for f in range(nfr):
+            seed = 47000 + 11 * f + N + L
+            msg, x, y, llr = frame(pc, ch, seed)
+            pc.message = np.zeros(N, dtype=int)
+            pc.message[pc.polarMask == 1] = msg
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                dec = np.asarray(pc.sclDecoderOracle(llr.copy()))
+            hit = [j for j, q in enumerate(pc.pathList) if (q.uHat == pc.message).all()]
+            first = pc.extract(pc.pathList[0].uHat)
+            seeds.append(seed)
+            decs.append(packbits(dec))
+            pml.append(np.array([float(q.pathMetric) for q in pc.pathList]))
+            uhl.append(np.stack([packbits(q.uHat) for q in pc.pathList]))
+            nerr.append(int(np.sum(np.abs(msg - dec))))
+            plain.append(int(np.sum(np.abs(msg - first))))
+            where.append(hit[0] if hit else -1)
+            cnts.append((pc.ANV, pc.sortNum, pc.unitCal))
+        out[f"{tag}_seeds"] = np.array(seeds, dtype=np.int64)
+        out[f"{tag}_dec"] = np.stack(decs)
+        out[f"{tag}_pm"] = np.stack(pml)
+        out[f"{tag}_uhat"] = np.stack(uhl)
+        out[f"{tag}_biterr"] = np.array(nerr, dtype=np.int64)
+        out[f"{tag}_biterr_first_path"] = np.array(plain, dtype=np.int64)
+        out[f"{tag}_truth_at"] = np.array(where, dtype=np.int64)
+        out[f"{tag}_counts"] = np.array(cnts, dtype=np.int64)
+        print(f"genie {tag}: {nfr} frames, {sum(e > 0 for e in nerr)} frame errors with the genie, "
+              f"{sum(e > 0 for e in plain)} with the first path, truth deeper than first in {sum(w > 0 for w in where)}, "
+              f"{time.time()-t0:.1f}s", flush=True)
+    np.savez_compressed(os.path.join(OUT, "genie.npz"), **out)
+
+
+SECTIONS = {"masks": gen_masks, "encoder": gen_encoder, "channel": gen_channel, "sc": gen_sc, "scl": gen_scl, "curves": gen_curves, "mainflow": gen_mainflow, "cascl": gen_cascl, "genie": gen_genie}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
