@@ -55,6 +55,11 @@ def lib():
         L.orc_genie_select.argtypes = [_u8p, C.c_int, C.c_int, _u8p]
         L.orc_mc_run_genie.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                        C.c_uint64, C.c_uint64, C.c_int64, _u64p]
+        _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+        L.orc_critical_set.argtypes = [_u8p, C.c_int, _i32p]
+        L.orc_modify_critical_set.argtypes = [_u8p, C.c_int, C.c_int, _i32p]
+        L.orc_pbf_decode_f64.argtypes = [_f64p, _u8p, C.c_int, C.c_uint64, C.c_int, _f64p, _u8p, _i32p]
+        L.orc_pbf_decode_f32.argtypes = [_f32p, _u8p, C.c_int, C.c_uint64, C.c_int, _f64p, _u8p, _i32p]
         L.orc_crc_encode.argtypes = [_u8p, C.c_int, C.c_uint64, _u8p]
         L.orc_ca_select.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_uint64]
         L.orc_mc_run_crc.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint64,
@@ -222,3 +227,32 @@ def mc_run_genie(mask, L, dtype, N0, seed, frame0, nframes):
     c = np.zeros(3, dtype=np.uint64)
     lib().orc_mc_run_genie(m, m.size, int(m.sum()), L, dtype, float(N0), seed, frame0, nframes, c)
     return c
+
+
+def critical_set(frozen):
+    fz = np.ascontiguousarray(np.asarray(frozen) != 0, dtype=np.uint8)
+    out = np.empty(fz.size, dtype=np.int32)
+    n = lib().orc_critical_set(fz, fz.size, out)
+    return out[:n].copy()
+
+
+def modify_critical_set(mask, i_max):
+    m = _mask(mask)
+    out = np.empty(m.size, dtype=np.int32)
+    n = lib().orc_modify_critical_set(m, m.size, int(i_max), out)
+    return out[:n].copy()
+
+
+def pbf_decode(llr, mask, crc_poly, max_level, mu):
+    """Single frame through progressive bit flipping.  Returns (information word [K] of the last SC run,
+    number of SC runs, flips of the last run)."""
+    m = _mask(mask)
+    llr = np.ascontiguousarray(llr)
+    mu = np.ascontiguousarray(mu, dtype=np.float64)
+    word = np.empty(int(m.sum()), dtype=np.uint8)
+    last = np.empty(max_level, dtype=np.int32)
+    if llr.dtype == np.float32:
+        runs = lib().orc_pbf_decode_f32(llr, m, m.size, int(crc_poly), max_level, mu, word, last)
+    else:
+        runs = lib().orc_pbf_decode_f64(llr.astype(np.float64, copy=False), m, m.size, int(crc_poly), max_level, mu, word, last)
+    return word, runs, last

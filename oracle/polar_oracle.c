@@ -609,3 +609,141 @@ ORC_API void orc_mc_run_genie(const uint8_t *mask, int N, int K, int L, int dtyp
     }
     free(info); free(x); free(uh); free(dec); free(ut); free(llr); free(pm); free(llrf);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Bit flipping
+ * ------------------------------------------------------------------------------------------------ */
+
+/* pcf.generateCriticalSet (cn/functions.py:279-310): table A of frozen-leaf counts per tree node; walking the
+ * levels from the root, every node without frozen leaves whose ancestors all had some contributes its first
+ * leaf and blanks its descendants.  frozen: N bytes, 1 = frozen.  Returns the count; out is ascending. */
+ORC_API int orc_critical_set(const uint8_t *frozen, int N, int32_t *out)
+{
+    int n = ilog2(N), cnt = 0;
+    int32_t **A = (int32_t **)malloc(sizeof(int32_t *) * (n + 1));
+    for (int i = 0; i <= n; i++) A[i] = (int32_t *)malloc(sizeof(int32_t) * ((size_t)1 << i));
+    for (int j = 0; j < N; j++) A[n][j] = frozen[j];
+    for (int i = n - 1; i >= 0; i--)
+        for (int j = 0; j < (1 << i); j++) A[i][j] = A[i + 1][2 * j] + A[i + 1][2 * j + 1];
+    for (int i = 0; i <= n; i++)
+        for (int j = 0; j < (1 << i); j++)
+            if (A[i][j] == 0) {
+                int i1 = j, i2 = j;
+                for (int k = 1; k <= n - i; k++) {
+                    i1 = 2 * i1;
+                    i2 = 2 * i2 + 1;
+                    for (int q = i1; q <= i2; q++) A[i + k][q] = -1;
+                }
+                out[cnt++] = i1;
+            }
+    for (int a = 1; a < cnt; a++) { /* criticalSet.sort() */
+        int32_t v = out[a];
+        int b = a - 1;
+        while (b >= 0 && out[b] > v) { out[b + 1] = out[b]; b--; }
+        out[b + 1] = v;
+    }
+    for (int i = 0; i <= n; i++) free(A[i]);
+    free(A);
+    return cnt;
+}
+
+/* pcf.modifyCriticalSet (cn/functions.py:312-319): the critical set of the code whose information bits are
+ * those of `mask` with index > iMax. */
+ORC_API int orc_modify_critical_set(const uint8_t *mask, int N, int iMax, int32_t *out)
+{
+    uint8_t *frozen = (uint8_t *)malloc((size_t)N);
+    for (int i = 0; i < N; i++) frozen[i] = (i > iMax && mask[i]) ? 0 : 1;
+    int c = orc_critical_set(frozen, N, out);
+    free(frozen);
+    return c;
+}
+
+static int crc_tail_zero(const uint8_t *word, int K, uint64_t crc_poly, uint8_t *scratch)
+{
+    int w = orc_crc_encode(word, K, crc_poly, scratch), sum = 0;
+    for (int t = 0; t < w; t++) sum += scratch[K + t];
+    return sum == 0;
+}
+
+/* Candidates ranked by |decision LLR| / sqrt(mu), ascending (cn/polarCode.py:1586-1590, 1606-1610; numpy's
+ * argsort is not stable, equal values keep index order here). */
+static void rank_candidates(int32_t *S, int ns, const double *decllr, const double *mu)
+{
+    double *M = (double *)malloc(sizeof(double) * (ns > 0 ? ns : 1));
+    for (int a = 0; a < ns; a++) M[a] = fabs(decllr[S[a]] / sqrt(mu[S[a]]));
+    for (int a = 1; a < ns; a++) {
+        int32_t v = S[a];
+        double m = M[a];
+        int b = a - 1;
+        while (b >= 0 && M[b] > m) { S[b + 1] = S[b]; M[b + 1] = M[b]; b--; }
+        S[b + 1] = v;
+        M[b + 1] = m;
+    }
+    free(M);
+}
+
+/* PolarCode.progressiveBitFlipping (cn/polarCode.py:1573-1628).  SC; while the CRC fails, the flip tree is
+ * searched level by level: level 0 = the critical set ranked by reliability, one SC run per node with that
+ * node's flips; a failing node at a level below the last spawns children (critical set of the information bits
+ * after its last flip, ranked with that run's decision LLRs) into the next level's queue.  The result is the
+ * information word of the LAST run made, successful or not.  word_out: K bits; last_seq: the flips of the last
+ * run, -1 padded to max_level; returns the number of SC runs. */
+#define DEFINE_PBF(REAL, SUF)                                                                         \
+    ORC_API int orc_pbf_decode_##SUF(const REAL *llr, const uint8_t *mask, int N, uint64_t crc_poly,  \
+                                     int max_level, const double *mu, uint8_t *word_out, int32_t *last_seq) \
+    {                                                                                                 \
+        uint8_t *uhat = malloc(N), *frozen = malloc(N), *scratch = malloc((size_t)N + 64);            \
+        REAL *dl = malloc(sizeof(REAL) * N);                                                          \
+        double *dld = malloc(sizeof(double) * N);                                                     \
+        int32_t *cand = malloc(sizeof(int32_t) * N);                                                  \
+        int runs = 0, K;                                                                              \
+        int32_t **seqs = calloc(max_level, sizeof(int32_t *));                                        \
+        int *count = calloc(max_level, sizeof(int)), *cap = calloc(max_level, sizeof(int));           \
+        for (int t = 0; t < max_level; t++) last_seq[t] = -1;                                         \
+        orc_sc_decode_##SUF(llr, mask, N, uhat, dl, NULL, 0);                                         \
+        runs++;                                                                                       \
+        K = orc_extract(uhat, mask, N, word_out);                                                     \
+        if (!crc_tail_zero(word_out, K, crc_poly, scratch)) {                                         \
+            for (int i = 0; i < N; i++) { frozen[i] = mask[i] ? 0 : 1; dld[i] = (double)dl[i]; }      \
+            int ns = orc_critical_set(frozen, N, cand);                                               \
+            rank_candidates(cand, ns, dld, mu);                                                       \
+            cap[0] = ns > 0 ? ns : 1;                                                                 \
+            seqs[0] = malloc(sizeof(int32_t) * max_level * cap[0]);                                   \
+            for (int a = 0; a < ns; a++) seqs[0][(size_t)a * max_level] = cand[a];                    \
+            count[0] = ns;                                                                            \
+            int l = 0, ok = 0;                                                                        \
+            while (l <= max_level - 1 && !ok) {                                                       \
+                for (int cur = 0; cur < count[l]; cur++) {                                            \
+                    const int32_t *seq = seqs[l] + (size_t)cur * max_level;                           \
+                    orc_sc_decode_##SUF(llr, mask, N, uhat, dl, seq, l + 1);                          \
+                    runs++;                                                                           \
+                    for (int t = 0; t < max_level; t++) last_seq[t] = t <= l ? seq[t] : -1;           \
+                    orc_extract(uhat, mask, N, word_out);                                             \
+                    if (crc_tail_zero(word_out, K, crc_poly, scratch)) { ok = 1; break; }             \
+                    if (l + 1 <= max_level - 1) {                                                     \
+                        for (int i = 0; i < N; i++) dld[i] = (double)dl[i];                           \
+                        int nc = orc_modify_critical_set(mask, N, seq[l], cand);                      \
+                        rank_candidates(cand, nc, dld, mu);                                           \
+                        if (count[l + 1] + nc > cap[l + 1]) {                                         \
+                            cap[l + 1] = 2 * (count[l + 1] + nc) + 16;                                \
+                            seqs[l + 1] = realloc(seqs[l + 1], sizeof(int32_t) * max_level * cap[l + 1]); \
+                            seq = seqs[l] + (size_t)cur * max_level;                                  \
+                        }                                                                             \
+                        for (int a = 0; a < nc; a++) {                                                \
+                            int32_t *dst = seqs[l + 1] + (size_t)(count[l + 1] + a) * max_level;      \
+                            for (int t = 0; t <= l; t++) dst[t] = seq[t];                             \
+                            dst[l + 1] = cand[a];                                                     \
+                        }                                                                             \
+                        count[l + 1] += nc;                                                           \
+                    }                                                                                 \
+                }                                                                                     \
+                l++;                                                                                  \
+            }                                                                                         \
+        }                                                                                             \
+        for (int t = 0; t < max_level; t++) free(seqs[t]);                                            \
+        free(seqs); free(count); free(cap); free(uhat); free(frozen); free(scratch); free(dl); free(dld); free(cand); \
+        return runs;                                                                                  \
+    }
+
+DEFINE_PBF(double, f64)
+DEFINE_PBF(float, f32)

@@ -440,7 +440,88 @@ def gen_genie(functions, polarCode, channel):
     np.savez_compressed(os.path.join(OUT, "genie.npz"), **out)
 
 
-SECTIONS = {"masks": gen_masks, "encoder": gen_encoder, "channel": gen_channel, "sc": gen_sc, "scl": gen_scl, "curves": gen_curves, "mainflow": gen_mainflow, "cascl": gen_cascl, "genie": gen_genie}
+# --------------------------------------------------------------------------- N4: bit flipping
+def gen_pbf(functions, polarCode, channel):
+    """generateCriticalSet / modifyCriticalSet / constructTree, scDecoder with a flip list, and frames decoded
+    by progressiveBitFlipping (cn/polarCode.py:1573-1628) with the number of SC runs each took."""
+    out = {}
+    for (N, K, cons) in [(128, 72, "dega"), (256, 136, "dega"), (1024, 536, "dega"), (512, 256, "rmpolar"), (64, 20, "dega")]:
+        mask = np.asarray(functions.degaBuild(N, K, 2.0) if cons == "dega" else functions.rmPolarBuild(N, K, 2.0))
+        cs = functions.generateCriticalSet((mask + 1) % 2)
+        out[f"crit_{cons}_{N}_{K}"] = np.asarray(cs, dtype=np.int64)
+        A = np.flatnonzero(mask)
+        for t in (0, len(A) // 3, len(A) - 2):
+            out[f"crit_{cons}_{N}_{K}_after_{A[t]}"] = np.asarray(functions.modifyCriticalSet(mask, A[t]), dtype=np.int64)
+    mask = np.asarray(functions.degaBuild(64, 20, 2.0))
+    tree = functions.constructTree(mask, 2)
+    out["tree_64_20_level0"] = np.array([nd.sequenceU for nd in tree[0]], dtype=np.int64)
+    out["tree_64_20_level1"] = np.array([nd.sequenceU for nd in tree[1]], dtype=np.int64)
+
+    # scDecoder(softMess, sequenceU)
+    pc = make_code(polarCode, functions, 128, 64, "dega", 2.0)
+    ch = channel.Channel("BPSK", 1.0, "SNRb", 0.5)
+    A = np.flatnonzero(pc.polarMask)
+    flips = [[int(A[3])], [int(A[5]), int(A[20])], [int(A[0]), int(A[1]), int(A[63])], [5]]  # 5 is a frozen index
+    uh, dl, fl = [], [], []
+    for f in range(16):
+        msg, x, y, llr = frame(pc, ch, 8100 + f)
+        seq = flips[f % len(flips)]
+        pc.scDecoder(llr.copy(), seq)
+        uh.append(packbits(pc.uHat))
+        dl.append(np.asarray(pc.llrs, dtype=np.float64))
+        fl.append(seq + [-1] * (3 - len(seq)))
+    out["flip_128_64_seeds"] = np.arange(8100, 8116, dtype=np.int64)
+    out["flip_128_64_uhat"] = np.stack(uh)
+    out["flip_128_64_decllr"] = np.stack(dl)
+    out["flip_128_64_seq"] = np.array(fl, dtype=np.int64)
+
+    cfgs = [(128, 72, 0x107, 8, 1, 1.5, 150), (128, 72, 0x107, 8, 2, 1.5, 60), (256, 136, 0x107, 8, 1, 1.5, 60),
+            (128, 72, 0x107, 8, 3, 2.0, 24), (128, 72, 0x107, 8, 3, 1.0, 8), (1024, 536, 0x1800063, 24, 1, 1.75, 30)]
+    for (N, K, poly, w, maxLevel, snr, nfr) in cfgs:
+        pc = make_code(polarCode, functions, N, K, "dega", 2.0)
+        pc.crcPoly, pc.crcWidth, pc.maxLevel = poly, w, maxLevel
+        ch = channel.Channel("BPSK", snr, "SNRb", (K - w) / N)
+        tag = f"{N}_{K}_w{w}_T{maxLevel}_{snr}"
+        calls = []
+        orig = polarCode.PolarCode.scDecoder
+
+        def counted(self, softMess, sequenceU=[]):
+            calls.append(list(sequenceU))
+            return orig(self, softMess, sequenceU)
+
+        polarCode.PolarCode.scDecoder = counted
+        seeds, decs, nerr, nrun, last, okl = [], [], [], [], [], []
+        t0 = time.time()
+        try:
+            for f in range(nfr):
+                seed = 52000 + 7 * f + N + maxLevel
+                np.random.seed(seed)
+                msg = np.random.randint(0, 2, size=K - w, dtype=int)
+                x = pc.CRCPolarEncode2(msg)
+                llr = np.asarray(ch.calcLLR(ch.addNoise(ch.modulate(x))), dtype=np.float64)
+                del calls[:]
+                dec = np.asarray(pc.progressiveBitFlipping(llr.copy()))
+                word = pc.extract(pc.uHat)
+                seeds.append(seed)
+                decs.append(packbits(dec))
+                nerr.append(int(np.sum(np.abs(msg - dec))))
+                nrun.append(len(calls))
+                last.append(calls[-1] + [-1] * (3 - len(calls[-1])))
+                okl.append(int(np.sum(functions.crcEncode(word, poly)[-w:]) == 0))
+        finally:
+            polarCode.PolarCode.scDecoder = orig
+        out[f"{tag}_seeds"] = np.array(seeds, dtype=np.int64)
+        out[f"{tag}_dec"] = np.stack(decs)
+        out[f"{tag}_biterr"] = np.array(nerr, dtype=np.int64)
+        out[f"{tag}_runs"] = np.array(nrun, dtype=np.int64)
+        out[f"{tag}_last_seq"] = np.array(last, dtype=np.int64)
+        out[f"{tag}_crc_ok"] = np.array(okl, dtype=np.int64)
+        print(f"pbf {tag}: {nfr} frames, {sum(e > 0 for e in nerr)} frame errors, {sum(r > 1 for r in nrun)} needed flips, "
+              f"max runs {max(nrun)}, {sum(1 - o for o in okl)} gave up, {time.time()-t0:.1f}s", flush=True)
+    np.savez_compressed(os.path.join(OUT, "pbf.npz"), **out)
+
+
+SECTIONS = {"masks": gen_masks, "encoder": gen_encoder, "channel": gen_channel, "sc": gen_sc, "scl": gen_scl, "curves": gen_curves, "mainflow": gen_mainflow, "cascl": gen_cascl, "genie": gen_genie, "pbf": gen_pbf}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
