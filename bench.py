@@ -337,6 +337,22 @@ def main():
             c3 = c3.cpu().tolist()
             extras["ca_scl8_1024_512_crc24"] = {"frames_per_s": nb / (li["last_ms"] * 1e-3), "info_mbps": nb * 512 / (li["last_ms"] * 1e-3) / 1e6,
                                                 "kernel": li["kernel"], "kernel_ms": li["last_ms"], "frames": nb, "fer": c3[1] / nb}
+            # progressive bit flipping on the same frames: fast SC on all, CRC test, flip search on the failures
+            cca.set_reliability(pcf.GA(1024, 536, 2.0))
+            for T, nb in ((1, 1 << 20), (2, 1 << 15)):  # a failing frame costs ~10^2 SC runs at T = 1, ~10^4 at T = 2
+                rn = torch.zeros(nb, dtype=torch.int32, device=dev)
+                cca.pbf_decode_dev(lca.data_ptr(), np.float32, T, hca.data_ptr(), nb, runs_ptr=rn.data_ptr())
+                ctx.sync()
+                t0 = time.perf_counter()
+                cca.pbf_decode_dev(lca.data_ptr(), np.float32, T, hca.data_ptr(), nb, runs_ptr=rn.data_ptr())
+                ctx.sync()
+                pdt = time.perf_counter() - t0
+                c3 = torch.zeros(3, dtype=torch.int64, device=dev)
+                cca.count_errors_dev(ica.data_ptr(), hca.data_ptr(), nb, c3.data_ptr(), crc=True)
+                ctx.sync()
+                extras["pbf_T%d_1024_512_crc24" % T] = {"frames_per_s": nb / pdt, "info_mbps": nb * 512 / pdt / 1e6, "frames": nb,
+                                                        "fer": c3.cpu().tolist()[1] / nb, "mean_sc_runs": float(rn.float().mean().item()),
+                                                        "max_sc_runs": int(rn.max().item()), "search_kernel_ms": cca.last_launch()["last_ms"]}
             del ica, hca, lca
         except _native.PolarError as e:
             extras["ca_scl8_1024_512_crc24"] = {"error": str(e)}

@@ -33,7 +33,7 @@ typedef struct polar_code polar_code;
 
 enum { POLAR_HOST = 0, POLAR_DEVICE = 1 };
 enum { POLAR_F32 = 0, POLAR_F64 = 1 };
-enum { POLAR_DEC_SC = 0, POLAR_DEC_SCL = 1 };
+enum { POLAR_DEC_SC = 0, POLAR_DEC_SCL = 1, POLAR_DEC_PBF = 2 };
 enum {
     POLAR_OK = 0,
     POLAR_EINVAL = -1,   /* bad argument */
@@ -140,6 +140,30 @@ int polar_scl_decode_genie(polar_code *code, const void *llr, int dtype, int L, 
 int polar_scl_decode_genie_packed(polar_code *code, const void *llr, int dtype, int L, const uint32_t *info_true,
                                   uint32_t *info_hat, double *pm_sorted, uint32_t *u_hat_all, int64_t B, int space);
 
+/* ---- bit flipping ---------------------------------------------------------------------------------
+ *      Host-only: pcf.generateCriticalSet((polarMask + 1) % 2) for after < 0, pcf.modifyCriticalSet(polarMask,
+ *      after) otherwise (cn/functions.py:279-319): first positions of the maximal all-information subtrees,
+ *      ascending, into out[0..cap); returns their number or a negative error code.  Needs no GPU. */
+int polar_critical_set(const uint8_t *mask, int N, int after, int32_t *out, int cap);
+/* Mean LLRs of the bit channels that rank the flip candidates, mu = pcfun.GA(N, K, designSNR)
+ * (cn/polarCode.py:1579): N doubles, host memory. */
+int polar_code_set_reliability(polar_code *code, const double *mu);
+/* PolarCode.scDecoder(softMess, sequenceU) (cn/polarCode.py:1525-1571 with the hook at :1555-1558) for a batch:
+ * flips [B x 3] int32 holds each frame's sequenceU, unused entries -1; the decision at a listed position is
+ * inverted (frozen positions included, as in the reference).  Outputs as in polar_sc_decode. */
+int polar_sc_decode_flip(polar_code *code, const void *llr, int dtype, const int32_t *flips, uint8_t *info_hat,
+                         uint8_t *u_hat, void *dec_llr, int64_t B, int space);
+/* PolarCode.progressiveBitFlipping (cn/polarCode.py:1573-1628) for a batch; needs polar_code_set_crc and, for
+ * max_level >= 1, polar_code_set_reliability.  max_level = pcode.maxLevel in [0, 3] (0: SC and the CRC test only).
+ * info_hat [B x K]: information word of the last SC run made for the frame, CRC bits included (the reference
+ * returns it whether or not its CRC holds); runs [B]: SC runs the reference would have made (1 = no flipping);
+ * crc_ok [B]: 1 if the returned word passes the CRC; last_seq [B x 3]: flips of the last run, -1 padded.
+ * runs, crc_ok, last_seq may be NULL.  Frames whose first SC run passes the CRC never enter the search. */
+int polar_pbf_decode(polar_code *code, const void *llr, int dtype, int max_level, uint8_t *info_hat, int32_t *runs,
+                     uint8_t *crc_ok, int32_t *last_seq, int64_t B, int space);
+int polar_pbf_decode_packed(polar_code *code, const void *llr, int dtype, int max_level, uint32_t *info_hat,
+                            int32_t *runs, uint8_t *crc_ok, int32_t *last_seq, int64_t B, int space);
+
 /* ---- error counting: pcf.fails per frame (cn/functions.py:107-109) plus the fer/ber counters of the
  *      driver loop (cn/simulator.py:216-226).  Adds to counters[0..2] = frames, frame errors, bit errors
  *      (device uint64[3]).  Packed device buffers.  With POLAR_CRC only the K - width message bits count. */
@@ -151,7 +175,8 @@ int polar_count_errors(polar_code *code, const uint32_t *info_packed, const uint
  *      counters (host uint64[3]) are ADDED to. Frame f always sees the same inputs whatever the chunking
  *      or the number of GPUs, because the generator is keyed by the global frame index.
  *      flags: POLAR_SC_FAST (SC), POLAR_CRC (SCL: CRC-aided frames, selection and counting),
- *      POLAR_GENIE (SCL: genie-aided choice against the generated message). */
+ *      POLAR_GENIE (SCL: genie-aided choice against the generated message).
+ *      decoder POLAR_DEC_PBF: progressive bit flipping with L = max_level; needs POLAR_CRC. */
 int polar_mc_run(polar_code *code, int decoder, int L, int dtype, int flags, double N0, uint64_t seed,
                  uint64_t frame0, int64_t nframes, uint64_t counters[3]);
 

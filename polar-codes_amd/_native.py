@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libpolar_hip.so")
 
 HOST, DEVICE = 0, 1
 F32, F64 = 0, 1
-DEC_SC, DEC_SCL = 0, 1
+DEC_SC, DEC_SCL, DEC_PBF = 0, 1, 2
 SC_FAST = 1
 CRC = 2
 GENIE = 4
@@ -60,6 +60,11 @@ SIGNATURES = {
     "polar_scl_decode_packed": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _i64, _i, _i]),
     "polar_scl_decode_genie": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _i]),
     "polar_scl_decode_genie_packed": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _i]),
+    "polar_critical_set": (_i, [_vp, _i, _i, _vp, _i]),
+    "polar_code_set_reliability": (_i, [_vp, _vp]),
+    "polar_sc_decode_flip": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _i]),
+    "polar_pbf_decode": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _i]),
+    "polar_pbf_decode_packed": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _i]),
     "polar_count_errors": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "polar_mc_run": (_i, [_vp, _i, _i, _i, _i, _d, _u64, _u64, _i64, _vp]),
     "polar_last_launch": (_i, [_vp, C.POINTER(LaunchInfo)]),
@@ -169,6 +174,12 @@ class Code:
         _check(lib().polar_code_set_crc(self._h, int(crc_poly)))
         self.crc_width = lib().polar_code_crc_width(self._h)
 
+    def set_reliability(self, mu):
+        """Mean LLRs of the bit channels (functions.GA) that rank the flip candidates."""
+        mu = np.ascontiguousarray(mu, dtype=np.float64)
+        assert mu.size == self.N
+        _check(lib().polar_code_set_reliability(self._h, mu.ctypes.data))
+
     def last_launch(self):
         li = LaunchInfo()
         _check(lib().polar_last_launch(self._h, C.byref(li)))
@@ -240,6 +251,43 @@ class Code:
                                             _ptr(pm), _ptr(uh), B, HOST))
         return info, pm, uh
 
+    def sc_decode_flip(self, llr, flips, want_uhat=True, want_llrs=True):
+        """SC decoding with inverted decisions: flips [B, <=3] positions per frame, -1 = unused."""
+        llr = np.ascontiguousarray(np.atleast_2d(llr))
+        if llr.dtype not in (np.float32, np.float64):
+            llr = llr.astype(np.float64)
+        B = llr.shape[0]
+        fl = np.full((B, 3), -1, dtype=np.int32)
+        flips = np.atleast_2d(np.asarray(flips, dtype=np.int32))
+        if flips.size:
+            assert flips.shape[1] <= 3, "at most three flips per frame"
+            fl[:, :flips.shape[1]] = flips
+        info = np.empty((B, self.K), dtype=np.uint8)
+        uh = np.empty((B, self.N), dtype=np.uint8) if want_uhat else None
+        dl = np.empty((B, self.N), dtype=llr.dtype) if want_llrs else None
+        _check(lib().polar_sc_decode_flip(self._h, llr.ctypes.data, _dt(llr.dtype), fl.ctypes.data, info.ctypes.data, _ptr(uh),
+                                          _ptr(dl), B, HOST))
+        return info, uh, dl
+
+    def pbf_decode(self, llr, max_level):
+        """Progressive bit flipping.  Returns (info [B, K], runs [B], crc_ok [B], last_seq [B, 3])."""
+        llr = np.ascontiguousarray(np.atleast_2d(llr))
+        if llr.dtype not in (np.float32, np.float64):
+            llr = llr.astype(np.float64)
+        B = llr.shape[0]
+        assert llr.shape[1] == self.N
+        info = np.empty((B, self.K), dtype=np.uint8)
+        runs = np.empty(B, dtype=np.int32)
+        ok = np.empty(B, dtype=np.uint8)
+        last = np.empty((B, 3), dtype=np.int32)
+        _check(lib().polar_pbf_decode(self._h, llr.ctypes.data, _dt(llr.dtype), int(max_level), info.ctypes.data, runs.ctypes.data,
+                                      ok.ctypes.data, last.ctypes.data, B, HOST))
+        return info, runs, ok, last
+
+    def pbf_decode_dev(self, llr_ptr, dtype, max_level, info_hat_ptr, B, runs_ptr=None, ok_ptr=None, last_ptr=None):
+        _check(lib().polar_pbf_decode_packed(self._h, llr_ptr, _dt(dtype), int(max_level), info_hat_ptr, runs_ptr, ok_ptr, last_ptr,
+                                             B, DEVICE))
+
     def mc_run(self, decoder, L, dtype, N0, seed, frame0, nframes, fast=True, crc=False, genie=False):
         cnt = np.zeros(3, dtype=np.uint64)
         flags = (SC_FAST if (fast and decoder == DEC_SC) else 0) | (CRC if crc else 0) | (GENIE if genie else 0)
@@ -276,6 +324,16 @@ def schedule_build(mask, fast):
     out = np.empty(n, dtype=np.uint32)
     _check(min(0, lib().polar_schedule_build(m.ctypes.data, m.size, 1 if fast else 0, out.ctypes.data, n)))
     return out
+
+
+def critical_set(mask, after=-1):
+    """First positions of the maximal all-information subtrees of `mask` restricted to indices > after (host only)."""
+    m = np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8)
+    out = np.empty(m.size, dtype=np.int32)
+    n = lib().polar_critical_set(m.ctypes.data, m.size, int(after), out.ctypes.data, out.size)
+    if n < 0:
+        _check(n)
+    return out[:n].copy()
 
 
 def default_ctx(device=None):

@@ -74,8 +74,8 @@ extern "C" int polar_ctx_destroy(polar_ctx *c)
     if (!c) return POLAR_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = {&c->in_bytes, &c->out_bytes, &c->in_words, &c->out_words, &c->llr_buf, &c->aux_buf,
-                      &c->aux2_buf, &c->pm_buf,    &c->counters, &c->mc_info,   &c->mc_hat};
+    DevBuf *bufs[] = {&c->in_bytes, &c->out_bytes, &c->in_words, &c->out_words, &c->llr_buf,   &c->aux_buf,  &c->aux2_buf,
+                      &c->pm_buf,   &c->counters,  &c->mc_info,  &c->mc_hat,    &c->flip_rows, &c->flip_ctr, &c->flip_small};
     for (DevBuf *b : bufs) b->release();
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
@@ -212,6 +212,9 @@ extern "C" int polar_code_destroy(polar_code *c)
     uint32_t *ps[] = {c->d_maskw, c->d_rank, c->d_A, c->d_sched[0], c->d_sched[1], c->d_sched[2], c->d_sched[3], c->d_Asl, c->d_Asl8,
                       c->d_crcE, c->d_crcS};
     for (uint32_t *p : ps)
+        if (p) (void)hipFree(p);
+    void *qs[] = {c->d_S0, c->d_crit_off, c->d_crit_idx, c->d_sqrt_mu};
+    for (void *p : qs)
         if (p) (void)hipFree(p);
     delete c;
     return POLAR_OK;
@@ -563,6 +566,224 @@ extern "C" int polar_scl_decode_genie_packed(polar_code *c, const void *llr, int
     return scl_common(c, llr, dtype, L, info_hat, pm, u_hat_all, B, 0, space, true, info_true);
 }
 
+// ---------------------------------------------------------------------------------------------- bit flipping
+// First positions of the maximal subtrees whose leaves are all information bits with index > after.
+static void critical_heads(const std::vector<int> &pre, int lo, int size, int after, std::vector<int32_t> &out)
+{
+    const int ninfo = pre[lo + size] - pre[lo];
+    if (ninfo == 0) return;
+    if (ninfo == size) {
+        out.push_back(lo);
+        return;
+    }
+    critical_heads(pre, lo, size / 2, after, out);
+    critical_heads(pre, lo + size / 2, size / 2, after, out);
+}
+static std::vector<int32_t> critical_set(const uint8_t *mask, int N, int after)
+{
+    std::vector<int> pre(N + 1, 0);
+    for (int i = 0; i < N; i++) pre[i + 1] = pre[i] + ((mask[i] && i > after) ? 1 : 0);
+    std::vector<int32_t> out;
+    critical_heads(pre, 0, N, after, out);
+    return out;
+}
+
+extern "C" int polar_critical_set(const uint8_t *mask, int N, int after, int32_t *out, int cap)
+{
+    ARG_TRY(mask != nullptr, "mask is NULL");
+    ARG_TRY(N >= 2 && N <= 65536 && (N & (N - 1)) == 0, "N must be a power of two in [2, 65536]");
+    std::vector<int32_t> cs = critical_set(mask, N, after < 0 ? -1 : after);
+    if (out)
+        for (size_t i = 0; i < cs.size() && (int)i < cap; i++) out[i] = cs[i];
+    return (int)cs.size();
+}
+
+extern "C" int polar_code_set_reliability(polar_code *c, const double *mu)
+{
+    ARG_TRY(c && mu, "NULL argument");
+    HIP_TRY(hipSetDevice(c->ctx->device));
+    HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+    std::vector<double> s(c->N);
+    for (int i = 0; i < c->N; i++) {
+        ARG_TRY(mu[i] > 0, "mu must be positive");
+        s[i] = std::sqrt(mu[i]);
+    }
+    if (!c->d_sqrt_mu) HIP_TRY(hipMalloc((void **)&c->d_sqrt_mu, sizeof(double) * c->N));
+    HIP_TRY(hipMemcpy(c->d_sqrt_mu, s.data(), sizeof(double) * c->N, hipMemcpyHostToDevice));
+    c->have_mu = true;
+    return POLAR_OK;
+}
+
+// Candidate tables of the flip search; the per-position lists are only needed from two simultaneous flips on.
+static int ensure_flip_tables(polar_code *c, bool need_lists)
+{
+    if (!c->d_S0) {
+        std::vector<int32_t> s0 = critical_set(c->mask.data(), c->N, -1);
+        c->nS0 = (int)s0.size();
+        c->maxS = std::max(c->maxS, c->nS0);
+        if (s0.empty()) s0.push_back(0);
+        HIP_TRY(hipMalloc((void **)&c->d_S0, s0.size() * 4));
+        HIP_TRY(hipMemcpy(c->d_S0, s0.data(), s0.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (need_lists && !c->have_crit) {
+        std::vector<int32_t> off(c->N + 1, 0), idx;
+        for (int i = 0; i < c->N; i++) {
+            if (c->mask[i]) {
+                std::vector<int32_t> cs = critical_set(c->mask.data(), c->N, i);
+                idx.insert(idx.end(), cs.begin(), cs.end());
+                c->maxS = std::max(c->maxS, (int)cs.size());
+            }
+            off[i + 1] = (int32_t)idx.size();
+        }
+        if (idx.empty()) idx.push_back(0);
+        HIP_TRY(hipMalloc((void **)&c->d_crit_off, off.size() * 4));
+        HIP_TRY(hipMalloc((void **)&c->d_crit_idx, idx.size() * 4));
+        HIP_TRY(hipMemcpy(c->d_crit_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_crit_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice));
+        c->have_crit = true;
+    }
+    return POLAR_OK;
+}
+
+// Device-side body: fast SC on every frame, CRC test, search kernel on the frames that failed.
+// wi: packed information words out; d_runs / d_ok / d_last: device side outputs or NULL.
+static int pbf_device(polar_code *c, const void *dl, int dtype, int max_level, uint32_t *wi, int32_t *d_runs, uint8_t *d_ok,
+                      int32_t *d_last, int64_t nb)
+{
+    polar_ctx *ctx = c->ctx;
+    int rc;
+    if ((rc = ensure_flip_tables(c, max_level >= 2))) return rc;
+    if ((rc = ctx->flip_rows.reserve(nb * 4)) || (rc = ctx->flip_ctr.reserve(16))) return rc;
+    unsigned long long *ctr = ctx->flip_ctr.as<unsigned long long>();
+    HIP_TRY(hipMemsetAsync(ctr, 0, 16, ctx->stream));
+    if ((rc = launch_sc_decode(c, dl, dtype, wi, nullptr, nullptr, nb, POLAR_SC_FAST))) return rc;
+    if ((rc = launch_crc_filter(c, wi, ctx->flip_rows.as<uint32_t>(), ctr + 1, d_runs, d_ok, d_last, nb))) return rc;
+    if (max_level >= 1)
+        rc = launch_pbf(c, dl, dtype, ctx->flip_rows.as<uint32_t>(), ctr + 1, ctr, nullptr, max_level, true, wi, nullptr, nullptr,
+                        d_runs, d_ok, d_last, nb);
+    return rc;
+}
+
+static int pbf_common(polar_code *c, const void *llr, int dtype, int max_level, void *info_hat, int32_t *runs, uint8_t *crc_ok,
+                      int32_t *last_seq, int64_t B, int space, bool packed)
+{
+    CHECK_COMMON(c, B, space);
+    ARG_TRY(llr && info_hat, "NULL buffer");
+    ARG_TRY(dtype == POLAR_F32 || dtype == POLAR_F64, "dtype must be POLAR_F32 or POLAR_F64");
+    ARG_TRY(max_level >= 0 && max_level <= 3, "max_level must be in [0, 3]");
+    ARG_TRY(c->crc_w > 0, "bit flipping needs polar_code_set_crc first");
+    ARG_TRY(max_level == 0 || c->have_mu, "bit flipping needs polar_code_set_reliability first");
+    polar_ctx *ctx = c->ctx;
+    const size_t es = llr_size(dtype);
+    int rc;
+    const int64_t chunk = (space == POLAR_HOST) ? HOST_CHUNK : (int64_t)1 << 22;
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        const int64_t nb = std::min(chunk, B - b0);
+        const char *dl = (const char *)llr + b0 * c->N * es;
+        uint32_t *wi;
+        int32_t *d_runs = runs ? runs + b0 : nullptr, *d_last = last_seq ? last_seq + b0 * 3 : nullptr;
+        uint8_t *d_ok = crc_ok ? crc_ok + b0 : nullptr;
+        if (space == POLAR_HOST) {
+            if ((rc = ctx->llr_buf.reserve(nb * c->N * es)) || (rc = ctx->flip_small.reserve(nb * 17))) return rc;
+            HIP_TRY(hipMemcpyAsync(ctx->llr_buf.p, dl, nb * c->N * es, hipMemcpyHostToDevice, ctx->stream));
+            dl = ctx->llr_buf.as<char>();
+            d_runs = ctx->flip_small.as<int32_t>();
+            d_last = d_runs + nb;
+            d_ok = reinterpret_cast<uint8_t *>(d_last + 3 * nb);
+        }
+        if (packed && space == POLAR_DEVICE) {
+            wi = (uint32_t *)info_hat + b0 * c->Kw;
+        } else {
+            if ((rc = ctx->out_words.reserve(nb * c->Kw * 4))) return rc;
+            wi = ctx->out_words.as<uint32_t>();
+        }
+        if ((rc = pbf_device(c, dl, dtype, max_level, wi, d_runs, d_ok, d_last, nb))) return rc;
+        if (packed) {
+            if (space == POLAR_HOST)
+                HIP_TRY(hipMemcpyAsync((uint32_t *)info_hat + b0 * c->Kw, wi, nb * c->Kw * 4, hipMemcpyDeviceToHost, ctx->stream));
+        } else if (space == POLAR_HOST) {
+            if ((rc = ctx->out_bytes.reserve(nb * (size_t)c->K + 1))) return rc;
+            if ((rc = launch_unpack_bits(ctx, wi, ctx->out_bytes.as<uint8_t>(), nb, c->K))) return rc;
+            HIP_TRY(hipMemcpyAsync((uint8_t *)info_hat + b0 * c->K, ctx->out_bytes.p, nb * c->K, hipMemcpyDeviceToHost, ctx->stream));
+        } else {
+            if ((rc = launch_unpack_bits(ctx, wi, (uint8_t *)info_hat + b0 * c->K, nb, c->K))) return rc;
+        }
+        if (space == POLAR_HOST) {
+            if (runs) HIP_TRY(hipMemcpyAsync(runs + b0, d_runs, nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+            if (last_seq) HIP_TRY(hipMemcpyAsync(last_seq + b0 * 3, d_last, nb * 12, hipMemcpyDeviceToHost, ctx->stream));
+            if (crc_ok) HIP_TRY(hipMemcpyAsync(crc_ok + b0, d_ok, nb, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+    }
+    return POLAR_OK;
+}
+
+extern "C" int polar_pbf_decode(polar_code *c, const void *llr, int dtype, int max_level, uint8_t *info_hat, int32_t *runs,
+                                uint8_t *crc_ok, int32_t *last_seq, int64_t B, int space)
+{
+    return pbf_common(c, llr, dtype, max_level, info_hat, runs, crc_ok, last_seq, B, space, false);
+}
+extern "C" int polar_pbf_decode_packed(polar_code *c, const void *llr, int dtype, int max_level, uint32_t *info_hat,
+                                       int32_t *runs, uint8_t *crc_ok, int32_t *last_seq, int64_t B, int space)
+{
+    return pbf_common(c, llr, dtype, max_level, info_hat, runs, crc_ok, last_seq, B, space, true);
+}
+
+extern "C" int polar_sc_decode_flip(polar_code *c, const void *llr, int dtype, const int32_t *flips, uint8_t *info_hat,
+                                    uint8_t *u_hat, void *dec_llr, int64_t B, int space)
+{
+    CHECK_COMMON(c, B, space);
+    ARG_TRY(llr && flips, "NULL buffer");
+    ARG_TRY(dtype == POLAR_F32 || dtype == POLAR_F64, "dtype must be POLAR_F32 or POLAR_F64");
+    polar_ctx *ctx = c->ctx;
+    const size_t es = llr_size(dtype);
+    int rc;
+    if ((rc = ensure_flip_tables(c, false))) return rc;
+    const int64_t chunk = (space == POLAR_HOST) ? HOST_CHUNK : (int64_t)1 << 20;
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        const int64_t nb = std::min(chunk, B - b0);
+        const char *dl = (const char *)llr + b0 * c->N * es;
+        const int32_t *dfl = flips + b0 * 3;
+        char *ddec = dec_llr ? (char *)dec_llr + b0 * c->N * es : nullptr;
+        if ((rc = ctx->out_words.reserve(nb * c->Kw * 4)) || (rc = ctx->aux_buf.reserve(nb * c->Nw * 4)) || (rc = ctx->flip_ctr.reserve(16)))
+            return rc;
+        uint32_t *wi = ctx->out_words.as<uint32_t>(), *wu = u_hat ? ctx->aux_buf.as<uint32_t>() : nullptr;
+        if (space == POLAR_HOST) {
+            if ((rc = ctx->llr_buf.reserve(nb * c->N * es)) || (rc = ctx->flip_small.reserve(nb * 12))) return rc;
+            HIP_TRY(hipMemcpyAsync(ctx->llr_buf.p, dl, nb * c->N * es, hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(ctx->flip_small.p, dfl, nb * 12, hipMemcpyHostToDevice, ctx->stream));
+            dl = ctx->llr_buf.as<char>();
+            dfl = ctx->flip_small.as<int32_t>();
+            if (dec_llr) {
+                if ((rc = ctx->aux2_buf.reserve(nb * c->N * es))) return rc;
+                ddec = ctx->aux2_buf.as<char>();
+            }
+        }
+        unsigned long long *ctr = ctx->flip_ctr.as<unsigned long long>();
+        HIP_TRY(hipMemsetAsync(ctr, 0, 16, ctx->stream));
+        if ((rc = launch_pbf(c, dl, dtype, nullptr, nullptr, ctr, dfl, 0, false, wi, wu, ddec, nullptr, nullptr, nullptr, nb))) return rc;
+        if (space == POLAR_HOST) {
+            if ((rc = ctx->out_bytes.reserve(nb * ((size_t)c->K + c->N) + 1))) return rc;
+            uint8_t *tb = ctx->out_bytes.as<uint8_t>();
+            if (info_hat) {
+                if ((rc = launch_unpack_bits(ctx, wi, tb, nb, c->K))) return rc;
+                if (c->K) HIP_TRY(hipMemcpyAsync(info_hat + b0 * c->K, tb, nb * c->K, hipMemcpyDeviceToHost, ctx->stream));
+            }
+            if (u_hat) {
+                uint8_t *tu = tb + nb * c->K;
+                if ((rc = launch_unpack_bits(ctx, wu, tu, nb, c->N))) return rc;
+                HIP_TRY(hipMemcpyAsync(u_hat + b0 * c->N, tu, nb * c->N, hipMemcpyDeviceToHost, ctx->stream));
+            }
+            if (dec_llr) HIP_TRY(hipMemcpyAsync((char *)dec_llr + b0 * c->N * es, ddec, nb * c->N * es, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        } else {
+            if (info_hat && (rc = launch_unpack_bits(ctx, wi, info_hat + b0 * c->K, nb, c->K))) return rc;
+            if (u_hat && (rc = launch_unpack_bits(ctx, wu, u_hat + b0 * c->N, nb, c->N))) return rc;
+        }
+    }
+    return POLAR_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- counting / MC
 extern "C" int polar_count_errors(polar_code *c, const uint32_t *info, const uint32_t *hat, int64_t B, int flags,
                                   uint64_t *counters)
@@ -578,13 +799,19 @@ extern "C" int polar_mc_run(polar_code *c, int decoder, int L, int dtype, int fl
 {
     ARG_TRY(c != nullptr && counters != nullptr, "NULL argument");
     ARG_TRY(nframes >= 0, "nframes must be >= 0");
-    ARG_TRY(decoder == POLAR_DEC_SC || decoder == POLAR_DEC_SCL, "decoder must be POLAR_DEC_SC or POLAR_DEC_SCL");
+    ARG_TRY(decoder == POLAR_DEC_SC || decoder == POLAR_DEC_SCL || decoder == POLAR_DEC_PBF,
+            "decoder must be POLAR_DEC_SC, POLAR_DEC_SCL or POLAR_DEC_PBF");
     ARG_TRY(dtype == POLAR_F32 || dtype == POLAR_F64, "dtype must be POLAR_F32 or POLAR_F64");
     ARG_TRY(N0 > 0, "N0 must be positive");
     if (decoder == POLAR_DEC_SCL)
         ARG_TRY(L == 1 || L == 2 || L == 4 || L == 8 || L == 16 || L == 32, "L must be a power of two in [1, 32]");
     CRC_TRY(c, flags);
-    ARG_TRY(!((flags & POLAR_CRC) && decoder != POLAR_DEC_SCL), "POLAR_CRC goes with the list decoder");
+    ARG_TRY(!((flags & POLAR_CRC) && decoder == POLAR_DEC_SC), "POLAR_CRC goes with the list or the flip decoder");
+    if (decoder == POLAR_DEC_PBF) {
+        ARG_TRY(flags & POLAR_CRC, "POLAR_DEC_PBF needs POLAR_CRC");
+        ARG_TRY(L >= 0 && L <= 3, "POLAR_DEC_PBF: L is max_level in [0, 3]");
+        ARG_TRY(L == 0 || c->have_mu, "bit flipping needs polar_code_set_reliability first");
+    }
     ARG_TRY(!((flags & POLAR_GENIE) && decoder != POLAR_DEC_SCL), "POLAR_GENIE goes with the list decoder");
     ARG_TRY(!((flags & POLAR_GENIE) && (flags & POLAR_CRC)), "POLAR_GENIE and POLAR_CRC exclude each other");
     const bool crc = (flags & POLAR_CRC) != 0;
@@ -606,6 +833,8 @@ extern "C" int polar_mc_run(polar_code *c, int decoder, int L, int dtype, int fl
         if ((rc = launch_gen_frames(c, ctx->mc_info.as<uint32_t>(), ctx->llr_buf.p, dtype, N0, seed, frame0 + f0, nb, crc))) return rc;
         if (decoder == POLAR_DEC_SC)
             rc = launch_sc_decode(c, ctx->llr_buf.p, dtype, ctx->mc_hat.as<uint32_t>(), nullptr, nullptr, nb, flags);
+        else if (decoder == POLAR_DEC_PBF)
+            rc = pbf_device(c, ctx->llr_buf.p, dtype, L, ctx->mc_hat.as<uint32_t>(), nullptr, nullptr, nullptr, nb);
         else
             rc = launch_scl_decode(c, ctx->llr_buf.p, dtype, L, ctx->mc_hat.as<uint32_t>(), nullptr, nullptr, nb, crc,
                                    (flags & POLAR_GENIE) ? ctx->mc_info.as<uint32_t>() : nullptr);

@@ -71,6 +71,7 @@ struct polar_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // staging / scratch
     DevBuf in_bytes, out_bytes, in_words, out_words, llr_buf, aux_buf, aux2_buf, pm_buf, counters, mc_info, mc_hat;
+    DevBuf flip_rows, flip_ctr, flip_small;  // failing-frame list, {work counter, row count}, per-frame side outputs
 };
 
 struct polar_code {
@@ -91,6 +92,11 @@ struct polar_code {
     int crc_w = 0;
     uint32_t *d_crcE = nullptr;    // K - crc_w words: CRC bits (bit j = j-th appended bit) contributed by message bit k
     uint32_t *d_crcS = nullptr;    // K words: remainder contributed by bit k of the K-bit word (message + CRC)
+    // bit flipping: level-0 candidates, candidates after a flip at each position (CSR), sqrt of the mean LLRs
+    int32_t *d_S0 = nullptr, *d_crit_off = nullptr, *d_crit_idx = nullptr;
+    double *d_sqrt_mu = nullptr;
+    int nS0 = 0, maxS = 0;
+    bool have_mu = false, have_crit = false;
     polar_launch_info last{};
 };
 
@@ -113,6 +119,12 @@ int launch_scl_decode(polar_code *c, const void *llr, int dtype, int L, uint32_t
                       uint32_t *u_hat_all, int64_t B, bool crc, const uint32_t *truth);
 // nbits: leading bits of each K-bit word that are compared
 int launch_count_errors(polar_code *c, const uint32_t *info, const uint32_t *hat, int64_t B, uint64_t *counters, int nbits);
+
+int launch_pbf(polar_code *c, const void *llr, int dtype, const uint32_t *rows, const unsigned long long *nrows_dev,
+               unsigned long long *work, const int32_t *flips_in, int max_level, bool crc, uint32_t *info_hat, uint32_t *u_hat,
+               void *dec_llr, int32_t *runs, uint8_t *crc_ok, int32_t *last_seq, int64_t B);
+int launch_crc_filter(polar_code *c, const uint32_t *info_hat, uint32_t *rows, unsigned long long *nrows, int32_t *runs,
+                      uint8_t *crc_ok, int32_t *last_seq, int64_t B);
 
 // timing bracket around the dominant kernel of a call
 struct LaunchTimer {

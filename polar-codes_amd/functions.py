@@ -227,3 +227,54 @@ def getGC(KI, g):
         x[0] = 1
         right[i, :] = polynomialMod(x, g)
     return np.concatenate([np.eye(KI, dtype=int), right], axis=1)
+
+
+# ---------------- flip candidates (bit-flipping decoders) ----------------
+
+class Node:
+    """One node of the flip tree: the positions flipped together (cn/polarCode.py:8-12)."""
+
+    def __init__(self):
+        self.sequenceU = []
+
+
+def generateCriticalSet(frozenBits):
+    """First index of every maximal subtree of the code tree without frozen leaves, ascending
+    (cn/functions.py:279-310).  frozenBits: 1 = frozen."""
+    fz = np.asarray(frozenBits).astype(int)
+    heads = []
+
+    def visit(lo, size):
+        nf = int(fz[lo:lo + size].sum())
+        if nf == size:
+            return
+        if nf == 0:
+            heads.append(lo)
+            return
+        visit(lo, size // 2)
+        visit(lo + size // 2, size // 2)
+
+    visit(0, fz.size)
+    return np.array(heads, dtype=int)
+
+
+def modifyCriticalSet(polarMask, iMax):
+    """Critical set of the information bits after position iMax (cn/functions.py:312-319)."""
+    m = np.asarray(polarMask).astype(int).copy()
+    m[:int(iMax) + 1] = 0
+    return generateCriticalSet(1 - m)
+
+
+def constructTree(polarMask, maxLevel):
+    """All flip sequences up to maxLevel simultaneous flips, level by level (cn/functions.py:321-349)."""
+    polarMask = np.asarray(polarMask).astype(int)
+    nodes = [[] for _ in range(maxLevel)]
+    for lvl in range(maxLevel):
+        parents = [None] if lvl == 0 else nodes[lvl - 1]
+        for parent in parents:
+            cand = generateCriticalSet(1 - polarMask) if parent is None else modifyCriticalSet(polarMask, parent.sequenceU[-1])
+            for u in cand:
+                node = Node()
+                node.sequenceU = ([] if parent is None else list(parent.sequenceU)) + [int(u)]
+                nodes[lvl].append(node)
+    return nodes

@@ -71,6 +71,8 @@ class PolarCode:
         self.crcPoly = 0x0
         self.crcPolyArrayForm = []
         self.crcWidth = 0
+        self.maxLevel = 1
+        self.criticalSet = pcfun.generateCriticalSet(self.frozenMask)
         self.decoderType = "sc"
         self.dtype = np.float64  # arithmetic type of the decoders: float64 = parity with the reference
         # bitReversed = True reproduces the ordering of the reference's stand-alone script cn/main.py:233,255-273:
@@ -167,11 +169,19 @@ class PolarCode:
     def scDecoder(self, softMess, sequenceU=[]):
         """Successive cancellation (cn/polarCode.py:1525-1571).  Sets self.uHat, self.llrs (decision LLRs),
         self.ANV = N like the reference; returns the decoded information bits."""
-        if len(sequenceU):
-            raise NotImplementedError("bit flipping (sequenceU) is not provided")
         llr = self._llr(softMess)
         batch = llr.shape[:-1]
-        info, uh, dl = self._active.sc_decode(llr.reshape(-1, self.codewordLength), want_uhat=True, want_llrs=True)
+        if len(sequenceU):
+            # the flip hook (cn/polarCode.py:1555-1558): decisions at these positions are inverted.  One list for
+            # every frame, or one row per frame ([B, <=3], -1 = unused).
+            if self.bitReversed:
+                raise NotImplementedError("sequenceU together with the bit-reversed ordering is not provided")
+            seq = np.asarray(sequenceU, dtype=np.int32)
+            nfr = int(np.prod(batch, dtype=np.int64)) if batch else 1
+            seq = np.broadcast_to(seq, (nfr, seq.shape[-1]))
+            info, uh, dl = self.native.sc_decode_flip(llr.reshape(-1, self.codewordLength), seq)
+        else:
+            info, uh, dl = self._active.sc_decode(llr.reshape(-1, self.codewordLength), want_uhat=True, want_llrs=True)
         if self.bitReversed:  # decoder step i decided uHat[bitreversed(i)] (cn/main.py:256-273)
             uh = uh[:, self._rev]
             info = uh[:, self.polarMask == 1]
@@ -181,6 +191,26 @@ class PolarCode:
         self.mT = -6
         self.predictIdx = []
         return info.reshape(batch + (self.infoLen,)).astype(int)
+
+    def progressiveBitFlipping(self, softMess):
+        """Progressive bit flipping (cn/polarCode.py:1573-1628) with self.maxLevel simultaneous flips at most,
+        self.crcPoly / self.crcWidth and the Gaussian-approximation reliabilities of (N, infoLen, designSNR).
+        Returns the message bits of the last SC run made (the reference returns them whether or not the CRC
+        holds); sets self.scRuns (SC runs per frame), self.crcPass and self.lastSequenceU."""
+        if self.bitReversed:
+            raise NotImplementedError("bit flipping together with the bit-reversed ordering is not provided")
+        llr = self._llr(softMess)
+        batch = llr.shape[:-1]
+        self._attach_crc()
+        if getattr(self.native, "_mu_for", None) != (self.infoLen, self.designSNR):
+            self.native.set_reliability(pcfun.GA(self.codewordLength, self.infoLen, self.designSNR))
+            self.native._mu_for = (self.infoLen, self.designSNR)
+        info, runs, ok, last = self.native.pbf_decode(llr.reshape(-1, self.codewordLength), int(self.maxLevel))
+        self.scRuns = runs.reshape(batch) if batch else int(runs[0])
+        self.crcPass = ok.reshape(batch).astype(bool) if batch else bool(ok[0])
+        self.lastSequenceU = last.reshape(batch + (3,))
+        km = self.infoLen - self.crcWidth
+        return info[:, :km].reshape(batch + (km,)).astype(int)
 
     def sclDecoderOracle(self, softMess, isCRC=False, isRCPP=False):
         """Genie-aided list decoding (cn/polarCode.py:1267-1317), the decoder the reference's driver calls

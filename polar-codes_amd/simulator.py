@@ -70,9 +70,13 @@ def native_runner(pcode, decoder, L, dtype, crc=False, genie=False):
     """Default frame runner: polar_mc_run of the GPU library."""
     import _native
 
-    dec = _native.DEC_SCL if decoder == "scl" else _native.DEC_SC
+    dec = {"scl": _native.DEC_SCL, "pbf": _native.DEC_PBF}.get(decoder, _native.DEC_SC)
     if crc:
         pcode._attach_crc()
+    if decoder == "pbf":
+        import functions as pcf
+
+        pcode.native.set_reliability(pcf.GA(pcode.codewordLength, pcode.infoLen, pcode.designSNR))
 
     def run(N0, seed, frame0, nframes):
         return pcode.native.mc_run(dec, L, dtype, N0, seed, frame0, nframes, crc=crc, genie=genie)
@@ -101,14 +105,17 @@ def simulate(pcode, snrRange, frames=None, errCnt=100, minFrames=100000, maxFram
     decoder = (decoder or getattr(pcode, "decoderType", "sc") or "sc").lower()
     if decoder in ("scl-oracle", "scloracle", "genie"):
         decoder, genie = "scl", True
-    if decoder not in ("sc", "scl"):
+    if decoder in ("pbf", "progressivebitflipping"):
+        decoder, isCRC = "pbf", True
+        L = int(L if L is not None else getattr(pcode, "maxLevel", 1))
+    if decoder not in ("sc", "scl", "pbf"):
         raise NotImplementedError("decoder %r is not provided" % (decoder,))
     L = int(L if L is not None else (getattr(pcode, "L", 0) or 1))
     snrType = snrType or getattr(pcode, "snrType", "") or "SNRb"
     modu = modu or getattr(pcode, "modu", "") or "BPSK"
     isCRC = bool(getattr(pcode, "isCRC", False) if isCRC is None else isCRC)
-    if isCRC and decoder != "scl":
-        raise ValueError("isCRC needs the list decoder")
+    if isCRC and decoder == "sc":
+        raise ValueError("isCRC needs the list or the flip decoder")
     msgLen = pcode.infoLen - (pcode.crcWidth if isCRC else 0)
     rate = msgLen / pcode.codewordLength
     if genie and (decoder != "scl" or isCRC):
@@ -171,8 +178,8 @@ def main(argv=None):
     ap.add_argument("--K", type=int, default=512)
     ap.add_argument("--construct", default="dega")
     ap.add_argument("--dsnr", type=float, default=2.0)
-    ap.add_argument("--decoder", default="sc", choices=["sc", "scl", "scl-oracle"])
-    ap.add_argument("--L", type=int, default=8)
+    ap.add_argument("--decoder", default="sc", choices=["sc", "scl", "scl-oracle", "pbf"])
+    ap.add_argument("--L", type=int, default=8, help="list size (scl) or the largest number of simultaneous flips (pbf)")
     ap.add_argument("--snr", type=float, nargs="+", default=[1.0, 1.5, 2.0, 2.5, 3.0])
     ap.add_argument("--frames", type=int, default=None)
     ap.add_argument("--errCnt", type=int, default=100)
@@ -194,6 +201,8 @@ def main(argv=None):
     pc = PolarCode(a.N, a.K + width, a.construct, a.dsnr, listSize=a.L)
     pc.decoderType, pc.snrType, pc.modu = a.decoder, "SNRb", "BPSK"
     pc.crcPoly, pc.crcWidth, pc.isCRC = a.crc, width, width > 0
+    if a.decoder == "pbf":
+        pc.maxLevel = a.L
     res = simulate(pc, a.snr, frames=a.frames, errCnt=a.errCnt, minFrames=a.minFrames, seed=a.seed,
                    dtype=np.float64 if a.f64 else np.float32, dist=dist)
     if dist is None or dist.get_rank() == 0:
