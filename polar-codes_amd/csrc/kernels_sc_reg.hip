@@ -40,9 +40,35 @@ template <int P, bool SHORT, typename T> __device__ __forceinline__ uint32_t sub
     } else {
         constexpr uint32_t FULL = (1u << P) - 1u, HALF = (1u << (P / 2)) - 1u;
         constexpr int I = P == 16 ? 0 : P == 8 ? 1 : P == 4 ? 2 : 3;
-        if (SHORT && P >= 4 && P < 16) {
+        if (SHORT && P < 16) {
             if (mask == 0u) return 0u;
             if (mask == FULL) return pin(v < (T)0 ? 1u : 0u);
+            // only the last leaf carries information: every left child is all-frozen, so the node reduces to
+            // the g-chain with zero partial sums, hi + lo level by level, and one decision shared by all leaves
+            if (mask == (1u << (P - 1))) {
+                T s = v + partner<P>(v);
+                if constexpr (P >= 4) s = s + partner<P / 2>(s);
+                if constexpr (P >= 8) s = s + partner<P / 4>(s);
+                return pin(s < (T)0 ? 1u : 0u);
+            }
+            if constexpr (P == 4) {
+                // leaves 2, 3: the left pair is frozen, the right pair is decided by sign
+                if (mask == 0xCu) {
+                    const T s = v + partner<4>(v);
+                    return pin(s < (T)0 ? 1u : 0u);
+                }
+                // leaves 1, 2, 3: left pair = one decision on the sum of the two f outputs, right pair by sign
+                if (mask == 0xEu) {
+                    const T o4 = partner<4>(v);
+                    const T vl4 = f_fast(v, o4);
+                    const T sl = vl4 + partner<2>(vl4);
+                    const uint32_t xl4 = pin(sl < (T)0 ? 1u : 0u);
+                    const T lo4 = rc.up[I] ? o4 : v, hi4 = rc.up[I] ? v : o4;
+                    const T vr4 = g_fast(lo4, hi4, xl4);
+                    const uint32_t xr4 = pin(vr4 < (T)0 ? 1u : 0u);
+                    return xr4 ^ (xl4 & rc.lowmask[I]);
+                }
+            }
         }
         const T o = partner<P>(v);
         const T lo = rc.up[I] ? o : v, hi = rc.up[I] ? v : o;
