@@ -80,11 +80,54 @@ template <int P, bool SHORT, typename T> __device__ __forceinline__ uint32_t sub
     }
 }
 
+// The same decoder with the rate profile of the node known at compile time: no branch is left.
+template <int P, uint32_t MASK, typename T> __device__ __forceinline__ uint32_t sub_node_c(T v, const RowConst &rc)
+{
+    constexpr uint32_t FULL = (P >= 32) ? 0xFFFFFFFFu : ((1u << P) - 1u), HALF = (1u << (P / 2)) - 1u;
+    constexpr int I = P == 16 ? 0 : P == 8 ? 1 : P == 4 ? 2 : 3;
+    if constexpr (MASK == 0u) {
+        return 0u;
+    } else if constexpr (MASK == FULL) {
+        return pin(v < (T)0 ? 1u : 0u);
+    } else if constexpr (MASK == (1u << (P - 1))) {
+        T s = v + partner<P>(v);
+        if constexpr (P >= 4) s = s + partner<P / 2>(s);
+        if constexpr (P >= 8) s = s + partner<P / 4>(s);
+        if constexpr (P >= 16) s = s + partner<P / 8>(s);
+        return pin(s < (T)0 ? 1u : 0u);
+    } else {
+        constexpr uint32_t ML = MASK & HALF, MR = (MASK >> (P / 2)) & HALF;
+        const T o = partner<P>(v);
+        if constexpr (ML == 0u) {
+            // frozen left half: its partial sums are zero, the right half sees hi + lo
+            const T vr = v + o;
+            return sub_node_c<P / 2, MR>(vr, rc);
+        } else {
+            const T lo = rc.up[I] ? o : v, hi = rc.up[I] ? v : o;
+            const T vl = f_fast(v, o);
+            const uint32_t xl = sub_node_c<P / 2, ML>(vl, rc);
+            const T vr = g_fast(lo, hi, xl);
+            const uint32_t xr = sub_node_c<P / 2, MR>(vr, rc);
+            return xr ^ (xl & rc.lowmask[I]);
+        }
+    }
+}
+
+// The 25 rate profiles of a 16-leaf node that respect the partial order of the bit channels (an information
+// position implies every position reachable by setting a bit or moving a one towards the MSB); a code built from
+// any reliability ordering only has these, all-frozen and all-information.  Leaf i = bit i.
+#define POLAR_PROFILES16(X)                                                                                         \
+    X(1, 0x8000u) X(2, 0xC000u) X(3, 0xE000u) X(4, 0xE800u) X(5, 0xE880u) X(6, 0xF000u) X(7, 0xF800u) X(8, 0xF880u)   \
+    X(9, 0xFC00u) X(10, 0xFC80u) X(11, 0xFCC0u) X(12, 0xFE00u) X(13, 0xFE80u) X(14, 0xFEC0u) X(15, 0xFEE0u)          \
+    X(16, 0xFEE8u) X(17, 0xFF00u) X(18, 0xFF80u) X(19, 0xFFC0u) X(20, 0xFFE0u) X(21, 0xFFE8u) X(22, 0xFFF0u)         \
+    X(23, 0xFFF8u) X(24, 0xFFFCu) X(25, 0xFFFEu)
+
 typedef uint64_t ps_t;
 
-template <typename T, int NLOG> struct RegDec {
+template <typename T, int NLOG, bool KEEP = false> struct RegDec {
     static constexpr int S = 1 << (NLOG - 4);  // slice length per lane
     T R[S];                                    // level l (4 <= l < NLOG): 2^(l-4) values at offset 2^(l-4)
+    T CA[KEEP ? S / 2 : 1], CB[KEEP ? S / 2 : 1];  // KEEP: the channel slice stays in registers for the top-level g
     ps_t ps0, ps1;                             // partial sums (plane 0 / 1), same offsets, one bit per value
     ps_t root;
 
@@ -95,7 +138,15 @@ template <typename T, int NLOG> struct RegDec {
 #pragma unroll
         for (int j = 0; j < c; j++) {
             T a, b;
-            if constexpr (LEV == NLOG) {
+            if constexpr (LEV == NLOG && KEEP) {
+                if constexpr (IS_G) {
+                    a = CA[j];
+                    b = CB[j];
+                } else {
+                    a = CA[j] = chan_lane[16 * j];
+                    b = CB[j] = chan_lane[16 * (j + c)];
+                }
+            } else if constexpr (LEV == NLOG) {
                 a = chan_lane[16 * j];
                 b = chan_lane[16 * (j + c)];
             } else {
@@ -150,9 +201,9 @@ struct NodeClasses {
 // two-trip loop that is deliberately NOT unrolled: every level's code then exists exactly once in the
 // program (F, G, rate-0, rate-1, combine), the recursion is a fixed nest of NLOG-4 loops, and the
 // register array keeps fixed homes.
-template <int LEV, int NLOG, bool FAST, typename T>
-__device__ __forceinline__ void decode_node(RegDec<T, NLOG> &d, const NodeClasses &nc, uint32_t maskv, const T *chan_lane,
-                                            uint32_t idx, int plane, const RowConst &rc)
+template <int LEV, int NLOG, bool FAST, bool KEEP, typename T>
+__device__ __forceinline__ void decode_node(RegDec<T, NLOG, KEEP> &d, const NodeClasses &nc, uint32_t maskv, uint32_t pidv,
+                                            const T *chan_lane, uint32_t idx, int plane, const RowConst &rc)
 {
 #pragma nounroll
     for (uint32_t h = 0; h < 2; h++) {
@@ -170,20 +221,29 @@ __device__ __forceinline__ void decode_node(RegDec<T, NLOG> &d, const NodeClasse
                 // lane i of maskv holds word i of the rate profile; the index is wave-uniform
                 const uint32_t mw = (uint32_t)__builtin_amdgcn_readlane((int)maskv, (int)(cidx >> 1));
                 const uint32_t m16 = (mw >> (16 * (cidx & 1))) & 0xFFFFu;
-                const uint32_t x = sub_node<16, FAST>(d.R[1], m16, rc);
+                uint32_t x;
+                // lane i of pidv names the profile of 16-leaf node i (0: none of the compiled ones)
+                const uint32_t pid = FAST ? (uint32_t)__builtin_amdgcn_readlane((int)pidv, (int)cidx) : 0u;
+                switch (pid) {
+#define POLAR_CASE16(ID, MASK) \
+    case ID: x = sub_node_c<16, MASK>(d.R[1], rc); break;
+                    POLAR_PROFILES16(POLAR_CASE16)
+#undef POLAR_CASE16
+                default: x = sub_node<16, FAST>(d.R[1], m16, rc); break;
+                }
                 if (h) d.ps1 = (d.ps1 & ~(ps_t)2) | ((ps_t)x << 1);
                 else d.ps0 = (d.ps0 & ~(ps_t)2) | ((ps_t)x << 1);
             } else {
-                decode_node<LEV - 1, NLOG, FAST>(d, nc, maskv, chan_lane, cidx, (int)h, rc);
+                decode_node<LEV - 1, NLOG, FAST, KEEP>(d, nc, maskv, pidv, chan_lane, cidx, (int)h, rc);
             }
         }
     }
     d.template combine<LEV>(plane);
 }
 
-template <typename T, int NLOG, bool FAST>
-__global__ void __launch_bounds__(64, 4) sc_reg_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, NodeClasses nc,
-                                                    const uint32_t *__restrict__ Asl, uint32_t *__restrict__ info_hat, int64_t B,
+template <typename T, int NLOG, bool FAST, bool KEEP>
+__global__ void __launch_bounds__(64, KEEP ? 3 : 4) sc_reg_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, NodeClasses nc,
+                                                    const uint32_t *__restrict__ pid16, const uint32_t *__restrict__ Asl, uint32_t *__restrict__ info_hat, int64_t B,
                                                     int K, int Kw)
 {
     __shared__ uint32_t stage[4 * 16 * 2];  // per frame: 16 lanes x 64-bit slice of u_hat
@@ -191,7 +251,7 @@ __global__ void __launch_bounds__(64, 4) sc_reg_kernel(const T *__restrict__ llr
     const int lane = threadIdx.x;
     const int grp = lane >> 4;
     const int sub = lane & 15;
-    RegDec<T, NLOG> d;
+    RegDec<T, NLOG, KEEP> d;
     RowConst rc;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -199,6 +259,7 @@ __global__ void __launch_bounds__(64, 4) sc_reg_kernel(const T *__restrict__ llr
         rc.lowmask[i] = rc.up[i] ? 0u : 0xFFFFFFFFu;
     }
     const uint32_t maskv = maskw[(lane & 31) < (N / 32) ? (lane & 31) : 0];
+    const uint32_t pidv = pid16[lane < (N / 16) ? lane : 0];
 
     for (int64_t f0 = (int64_t)blockIdx.x * 4; f0 < B; f0 += (int64_t)gridDim.x * 4) {
         const int64_t f = f0 + grp;
@@ -207,7 +268,7 @@ __global__ void __launch_bounds__(64, 4) sc_reg_kernel(const T *__restrict__ llr
         const T *chan_lane = llr + fc * N + sub;
         d.ps0 = d.ps1 = 0;
         d.root = 0;
-        decode_node<NLOG, NLOG, FAST>(d, nc, maskv, chan_lane, 0u, 0, rc);
+        decode_node<NLOG, NLOG, FAST, KEEP>(d, nc, maskv, pidv, chan_lane, 0u, 0, rc);
 
         // u_hat = x_hat F^{(x)n} on the sliced layout: element k = sub + 16 j is bit j of lane sub.
         ps_t u = d.root;
@@ -259,6 +320,18 @@ __global__ void __launch_bounds__(64, 4) sc_reg_kernel(const T *__restrict__ llr
 }
 
 // ------------------------------------------------------------------------------------------ host side
+// Profile number (1..25) of a 16-leaf rate profile, 0 if it is not one of the compiled ones.
+uint32_t sc_reg_profile_id(uint32_t m16)
+{
+    switch (m16) {
+#define POLAR_ID16(ID, MASK) \
+    case MASK: return ID;
+        POLAR_PROFILES16(POLAR_ID16)
+#undef POLAR_ID16
+    default: return 0u;
+    }
+}
+
 static NodeClasses classify_nodes(const polar_code *c, bool fast)
 {
     NodeClasses nc;
@@ -287,11 +360,16 @@ bool sc_reg_supported(const polar_code *c, int dtype, const void *u_hat, const v
     return true;
 }
 
-template <typename T, int NLOG, bool FAST> static int launch_reg_t(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B)
+template <typename T, int NLOG, bool FAST, bool KEEP = false>
+static int launch_reg_t(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B)
 {
+    if constexpr (NLOG == 10 && FAST && !KEEP) {
+        const char *e = getenv("POLAR_SC_KEEP");
+        if (e && e[0] == '1') return launch_reg_t<T, NLOG, FAST, true>(c, llr, info_hat, B);
+    }
     polar_ctx *ctx = c->ctx;
     const NodeClasses nc = classify_nodes(c, FAST);
-    auto kern = sc_reg_kernel<T, NLOG, FAST>;
+    auto kern = sc_reg_kernel<T, NLOG, FAST, KEEP>;
     int occ = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, 0));
     if (occ < 1) occ = 1;
@@ -299,11 +377,11 @@ template <typename T, int NLOG, bool FAST> static int launch_reg_t(polar_code *c
     int64_t grid = std::min<int64_t>(need, (int64_t)ctx->num_cus * occ * 8);
     LaunchTimer tm(ctx);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), 0, ctx->stream, (const T *)llr, (const uint32_t *)c->d_maskw, nc,
-                       (const uint32_t *)c->d_Asl, info_hat, B, c->K, c->Kw);
+                       (const uint32_t *)c->d_pid16, (const uint32_t *)c->d_Asl, info_hat, B, c->K, c->Kw);
     HIP_TRY(hipGetLastError());
     float ms = tm.stop();
-    snprintf(c->last.kernel, sizeof(c->last.kernel), "sc_reg_kernel<%s,%d>%s", sizeof(T) == 4 ? "float" : "double", NLOG,
-             FAST ? "/fast" : "");
+    snprintf(c->last.kernel, sizeof(c->last.kernel), "sc_reg_kernel<%s,%d>%s%s", sizeof(T) == 4 ? "float" : "double", NLOG,
+             FAST ? "/fast" : "", KEEP ? "/keep" : "");
     c->last.lanes_per_frame = 16;
     c->last.lds_bytes_per_block = 512;
     c->last.block_threads = 64;

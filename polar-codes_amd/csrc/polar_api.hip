@@ -185,6 +185,12 @@ extern "C" int polar_code_create(polar_ctx *ctx, int N, const uint8_t *mask, pol
         uint32_t e = pos & 7u, q = e < 4 ? e : 11 - e;
         Asl8.push_back((q << 7) | (pos >> 3));
     }
+    std::vector<uint32_t> pid16(64, 0);
+    for (int b = 0; b < N / 16 && b < 64; b++) {
+        uint32_t m16 = 0;
+        for (int i = 0; i < 16; i++) m16 |= (uint32_t)c->mask[16 * b + i] << i;
+        pid16[b] = sc_reg_profile_id(m16);
+    }
     if (A.empty()) A.push_back(0);
     if (Asl.empty()) Asl.push_back(0);
     if (Asl8.empty()) Asl8.push_back(0);
@@ -196,7 +202,8 @@ extern "C" int polar_code_create(polar_ctx *ctx, int N, const uint8_t *mask, pol
     };
     int rc;
     if ((rc = up(&c->d_maskw, maskw)) || (rc = up(&c->d_rank, rank)) || (rc = up(&c->d_A, A)) ||
-        (rc = up(&c->d_sched[0], c->sched[0])) || (rc = up(&c->d_sched[1], c->sched[1])) || (rc = up(&c->d_Asl, Asl)) || (rc = up(&c->d_Asl8, Asl8))) {
+        (rc = up(&c->d_sched[0], c->sched[0])) || (rc = up(&c->d_sched[1], c->sched[1])) || (rc = up(&c->d_Asl, Asl)) || (rc = up(&c->d_Asl8, Asl8)) ||
+        (rc = up(&c->d_pid16, pid16))) {
         polar_code_destroy(c);
         return rc;
     }
@@ -210,7 +217,7 @@ extern "C" int polar_code_destroy(polar_code *c)
     (void)hipSetDevice(c->ctx->device);
     (void)hipStreamSynchronize(c->ctx->stream);
     uint32_t *ps[] = {c->d_maskw, c->d_rank, c->d_A, c->d_sched[0], c->d_sched[1], c->d_sched[2], c->d_sched[3], c->d_Asl, c->d_Asl8,
-                      c->d_crcE, c->d_crcS};
+                      c->d_crcE, c->d_crcS, c->d_pid16};
     for (uint32_t *p : ps)
         if (p) (void)hipFree(p);
     void *qs[] = {c->d_S0, c->d_crit_off, c->d_crit_idx, c->d_sqrt_mu};

@@ -86,6 +86,7 @@ struct polar_code {
     uint32_t *d_A = nullptr;       // K info positions, ascending
     uint32_t *d_sched[4] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t *d_Asl8 = nullptr;    // same for the 8-lanes-per-path layout: (lane-in-path << 7) | bit
+    uint32_t *d_pid16 = nullptr;   // 64 words: compiled-profile number of each 16-leaf node (register SC kernel)
     uint32_t *d_Asl = nullptr;     // K entries: (lane << 6) | bit of each info position in the sliced layout
     // CRC (0 = none): generator with leading term, degree, and the two linear maps of the remainder
     uint64_t crc_poly = 0;
@@ -110,6 +111,7 @@ int launch_gen_frames(polar_code *c, uint32_t *info, void *llr, int dtype, doubl
                       uint64_t frame0, int64_t B, bool crc);
 int launch_sc_decode(polar_code *c, const void *llr, int dtype, uint32_t *info_hat, uint32_t *u_hat,
                      void *dec_llr, int64_t B, int flags);
+uint32_t sc_reg_profile_id(uint32_t m16);
 bool sc_reg_supported(const polar_code *c, int dtype, const void *u_hat, const void *dec_llr);
 int launch_sc_reg(polar_code *c, const void *llr, int dtype, uint32_t *info_hat, int64_t B, int flags);
 bool scl_reg_supported(const polar_code *c, int dtype, int L, const void *pm, const void *u_hat_all);
