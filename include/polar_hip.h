@@ -82,7 +82,8 @@ int polar_code_crc_width(const polar_code *code);
 
 /* Host-only: writes the decoder schedule compiled from `mask` (one 32-bit word per operation, see
  * polar-codes_amd/csrc/polar_internal.h for the encoding) into out[0..cap) and returns its length, or a
- * negative error code.  Needs no GPU. */
+ * negative error code.  fast: bit 0 = short-cut all-frozen / all-information subtrees, bit 1 = 16-leaf nodes as
+ * single in-register operations.  Needs no GPU. */
 int polar_schedule_build(const uint8_t *mask, int N, int fast, uint32_t *out, int cap);
 
 /* ---- encoder: PolarCode.polarEncode = mul_matrix(rateProfile(info)) (cn/polarCode.py:225-255).

@@ -315,14 +315,15 @@ class Code:
         _check(lib().polar_count_errors(self._h, info_ptr, hat_ptr, B, CRC if crc else 0, counters_ptr))
 
 
-def schedule_build(mask, fast):
+def schedule_build(mask, fast, sub16=False):
     """Decoder schedule for a rate profile as a uint32 array (host only, no GPU needed)."""
     m = np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8)
-    n = lib().polar_schedule_build(m.ctypes.data, m.size, 1 if fast else 0, None, 0)
+    fast = (1 if fast else 0) | (2 if sub16 else 0)
+    n = lib().polar_schedule_build(m.ctypes.data, m.size, fast, None, 0)
     if n < 0:
         _check(n)
     out = np.empty(n, dtype=np.uint32)
-    _check(min(0, lib().polar_schedule_build(m.ctypes.data, m.size, 1 if fast else 0, out.ctypes.data, n)))
+    _check(min(0, lib().polar_schedule_build(m.ctypes.data, m.size, fast, out.ctypes.data, n)))
     return out
 
 

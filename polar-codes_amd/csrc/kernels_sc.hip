@@ -15,6 +15,7 @@
 #include <algorithm>
 
 #include "decode_common.h"
+#include "reg_common.h"
 #include "polar_internal.h"
 
 template <typename T> struct SCParams {
@@ -41,6 +42,12 @@ template <typename T, int G> __global__ void __launch_bounds__(64) sc_decode_ker
     uint32_t *p0 = reinterpret_cast<uint32_t *>(base + (size_t)p.N * sizeof(T));
     uint32_t *p1 = p0 + 2 * p.Nw;
     const int N = p.N, n = p.n, Nw = p.Nw;
+    RowConst rc;  // position of this lane in its 16-lane row, for the in-register 16-leaf nodes
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        rc.up[i] = (lane & (8 >> i)) != 0;
+        rc.lowmask[i] = rc.up[i] ? 0u : 0xFFFFFFFFu;
+    }
 
     for (int64_t f0 = (int64_t)blockIdx.x * FPW; f0 < p.B; f0 += (int64_t)gridDim.x * FPW) {
         const int64_t f = f0 + grp;
@@ -88,6 +95,18 @@ template <typename T, int G> __global__ void __launch_bounds__(64) sc_decode_ker
                 if (plane) nar1 = (nar1 & ~2u) | (bit << 1);
                 else nar0 = (nar0 & ~2u) | (bit << 1);
                 if (p.dec_llr && sub == 0 && active) p.dec_llr[f * N + OP_LEAFIDX(op)] = v;
+                break;
+            }
+            case OP_SUB16: {
+                // the node's 16 LLRs, one per lane of a row (every row of the group does the same work), are
+                // decoded by the replicated butterfly; lane e of the row ends up with partial-sum bit e
+                if constexpr (G >= 16) {
+                    const T v = lv[16 + (lane & 15)];
+                    const uint32_t x = sub_node<16, true>(v, OP_LEAFIDX(op) & 0xFFFFu, rc);
+                    const uint32_t bits = (uint32_t)group_ballot<G>(x != 0u, grp) & 0xFFFFu;
+                    if (plane) nar1 = (nar1 & 0x0000FFFFu) | (bits << 16);
+                    else nar0 = (nar0 & 0x0000FFFFu) | (bits << 16);
+                }
                 break;
             }
             case OP_R0: {
@@ -209,7 +228,10 @@ static int launch_sc_t(polar_code *c, const void *llr, uint32_t *info_hat, uint3
     constexpr int FPW = 64 / G;
     SCParams<T> p;
     p.llr = (const T *)llr;
-    p.ops = c->d_sched[(flags & POLAR_SC_FAST) ? 1 : 0];
+    // 16-leaf nodes run as single in-register operations unless the caller wants the per-leaf decision LLRs
+    // or the group is narrower than a 16-lane row
+    const bool sub16 = (G >= 16) && dec_llr == nullptr && c->n >= 5;
+    p.ops = c->d_sched[((flags & POLAR_SC_FAST) ? 1 : 0) + (sub16 ? 2 : 0)];
     p.A = c->d_A;
     p.info_hat = info_hat;
     p.u_hat = u_hat;

@@ -22,112 +22,11 @@
 #include "reg_common.h"
 #include "polar_internal.h"
 
-// Lane constants of the replicated butterfly: for period P, lanes whose element index is in the upper half.
-struct RowConst {
-    uint32_t lowmask[4];  // P = 16, 8, 4, 2: all-ones when (sub & P/2) == 0
-    bool up[4];
-};
-
-// Decodes a node of P leaves whose P LLRs are replicated with period P over the row.
-// mask: P bits (wave-uniform), bit i = leaf i carries information.  Returns the node's partial-sum bit of
-// element (sub mod P) as an integer 0/1.  SHORT enables the rate-0 / rate-1 short-cuts at P = 8 and 4
-// (same decisions).
-template <int P, bool SHORT, typename T> __device__ __forceinline__ uint32_t sub_node(T v, uint32_t mask, const RowConst &rc)
-{
-    if constexpr (P == 1) {
-        const uint32_t neg = pin(v < (T)0 ? 1u : 0u);
-        return neg & mask;  // mask is the single (uniform) info bit
-    } else {
-        constexpr uint32_t FULL = (1u << P) - 1u, HALF = (1u << (P / 2)) - 1u;
-        constexpr int I = P == 16 ? 0 : P == 8 ? 1 : P == 4 ? 2 : 3;
-        if (SHORT && P < 16) {
-            if (mask == 0u) return 0u;
-            if (mask == FULL) return pin(v < (T)0 ? 1u : 0u);
-            // only the last leaf carries information: every left child is all-frozen, so the node reduces to
-            // the g-chain with zero partial sums, hi + lo level by level, and one decision shared by all leaves
-            if (mask == (1u << (P - 1))) {
-                T s = v + partner<P>(v);
-                if constexpr (P >= 4) s = s + partner<P / 2>(s);
-                if constexpr (P >= 8) s = s + partner<P / 4>(s);
-                return pin(s < (T)0 ? 1u : 0u);
-            }
-            if constexpr (P == 4) {
-                // leaves 2, 3: the left pair is frozen, the right pair is decided by sign
-                if (mask == 0xCu) {
-                    const T s = v + partner<4>(v);
-                    return pin(s < (T)0 ? 1u : 0u);
-                }
-                // leaves 1, 2, 3: left pair = one decision on the sum of the two f outputs, right pair by sign
-                if (mask == 0xEu) {
-                    const T o4 = partner<4>(v);
-                    const T vl4 = f_fast(v, o4);
-                    const T sl = vl4 + partner<2>(vl4);
-                    const uint32_t xl4 = pin(sl < (T)0 ? 1u : 0u);
-                    const T lo4 = rc.up[I] ? o4 : v, hi4 = rc.up[I] ? v : o4;
-                    const T vr4 = g_fast(lo4, hi4, xl4);
-                    const uint32_t xr4 = pin(vr4 < (T)0 ? 1u : 0u);
-                    return xr4 ^ (xl4 & rc.lowmask[I]);
-                }
-            }
-        }
-        const T o = partner<P>(v);
-        const T lo = rc.up[I] ? o : v, hi = rc.up[I] ? v : o;
-        const T vl = f_fast(v, o);
-        const uint32_t xl = sub_node<P / 2, SHORT>(vl, mask & HALF, rc);
-        const T vr = g_fast(lo, hi, xl);
-        const uint32_t xr = sub_node<P / 2, SHORT>(vr, (mask >> (P / 2)) & HALF, rc);
-        return xr ^ (xl & rc.lowmask[I]);
-    }
-}
-
-// The same decoder with the rate profile of the node known at compile time: no branch is left.
-template <int P, uint32_t MASK, typename T> __device__ __forceinline__ uint32_t sub_node_c(T v, const RowConst &rc)
-{
-    constexpr uint32_t FULL = (P >= 32) ? 0xFFFFFFFFu : ((1u << P) - 1u), HALF = (1u << (P / 2)) - 1u;
-    constexpr int I = P == 16 ? 0 : P == 8 ? 1 : P == 4 ? 2 : 3;
-    if constexpr (MASK == 0u) {
-        return 0u;
-    } else if constexpr (MASK == FULL) {
-        return pin(v < (T)0 ? 1u : 0u);
-    } else if constexpr (MASK == (1u << (P - 1))) {
-        T s = v + partner<P>(v);
-        if constexpr (P >= 4) s = s + partner<P / 2>(s);
-        if constexpr (P >= 8) s = s + partner<P / 4>(s);
-        if constexpr (P >= 16) s = s + partner<P / 8>(s);
-        return pin(s < (T)0 ? 1u : 0u);
-    } else {
-        constexpr uint32_t ML = MASK & HALF, MR = (MASK >> (P / 2)) & HALF;
-        const T o = partner<P>(v);
-        if constexpr (ML == 0u) {
-            // frozen left half: its partial sums are zero, the right half sees hi + lo
-            const T vr = v + o;
-            return sub_node_c<P / 2, MR>(vr, rc);
-        } else {
-            const T lo = rc.up[I] ? o : v, hi = rc.up[I] ? v : o;
-            const T vl = f_fast(v, o);
-            const uint32_t xl = sub_node_c<P / 2, ML>(vl, rc);
-            const T vr = g_fast(lo, hi, xl);
-            const uint32_t xr = sub_node_c<P / 2, MR>(vr, rc);
-            return xr ^ (xl & rc.lowmask[I]);
-        }
-    }
-}
-
-// The 25 rate profiles of a 16-leaf node that respect the partial order of the bit channels (an information
-// position implies every position reachable by setting a bit or moving a one towards the MSB); a code built from
-// any reliability ordering only has these, all-frozen and all-information.  Leaf i = bit i.
-#define POLAR_PROFILES16(X)                                                                                         \
-    X(1, 0x8000u) X(2, 0xC000u) X(3, 0xE000u) X(4, 0xE800u) X(5, 0xE880u) X(6, 0xF000u) X(7, 0xF800u) X(8, 0xF880u)   \
-    X(9, 0xFC00u) X(10, 0xFC80u) X(11, 0xFCC0u) X(12, 0xFE00u) X(13, 0xFE80u) X(14, 0xFEC0u) X(15, 0xFEE0u)          \
-    X(16, 0xFEE8u) X(17, 0xFF00u) X(18, 0xFF80u) X(19, 0xFFC0u) X(20, 0xFFE0u) X(21, 0xFFE8u) X(22, 0xFFF0u)         \
-    X(23, 0xFFF8u) X(24, 0xFFFCu) X(25, 0xFFFEu)
-
 typedef uint64_t ps_t;
 
-template <typename T, int NLOG, bool KEEP = false> struct RegDec {
+template <typename T, int NLOG> struct RegDec {
     static constexpr int S = 1 << (NLOG - 4);  // slice length per lane
     T R[S];                                    // level l (4 <= l < NLOG): 2^(l-4) values at offset 2^(l-4)
-    T CA[KEEP ? S / 2 : 1], CB[KEEP ? S / 2 : 1];  // KEEP: the channel slice stays in registers for the top-level g
     ps_t ps0, ps1;                             // partial sums (plane 0 / 1), same offsets, one bit per value
     ps_t root;
 
@@ -138,15 +37,7 @@ template <typename T, int NLOG, bool KEEP = false> struct RegDec {
 #pragma unroll
         for (int j = 0; j < c; j++) {
             T a, b;
-            if constexpr (LEV == NLOG && KEEP) {
-                if constexpr (IS_G) {
-                    a = CA[j];
-                    b = CB[j];
-                } else {
-                    a = CA[j] = chan_lane[16 * j];
-                    b = CB[j] = chan_lane[16 * (j + c)];
-                }
-            } else if constexpr (LEV == NLOG) {
+            if constexpr (LEV == NLOG) {
                 a = chan_lane[16 * j];
                 b = chan_lane[16 * (j + c)];
             } else {
@@ -201,8 +92,8 @@ struct NodeClasses {
 // two-trip loop that is deliberately NOT unrolled: every level's code then exists exactly once in the
 // program (F, G, rate-0, rate-1, combine), the recursion is a fixed nest of NLOG-4 loops, and the
 // register array keeps fixed homes.
-template <int LEV, int NLOG, bool FAST, bool KEEP, typename T>
-__device__ __forceinline__ void decode_node(RegDec<T, NLOG, KEEP> &d, const NodeClasses &nc, uint32_t maskv, uint32_t pidv,
+template <int LEV, int NLOG, bool FAST, typename T>
+__device__ __forceinline__ void decode_node(RegDec<T, NLOG> &d, const NodeClasses &nc, uint32_t maskv, uint32_t pidv,
                                             const T *chan_lane, uint32_t idx, int plane, const RowConst &rc)
 {
 #pragma nounroll
@@ -234,15 +125,15 @@ __device__ __forceinline__ void decode_node(RegDec<T, NLOG, KEEP> &d, const Node
                 if (h) d.ps1 = (d.ps1 & ~(ps_t)2) | ((ps_t)x << 1);
                 else d.ps0 = (d.ps0 & ~(ps_t)2) | ((ps_t)x << 1);
             } else {
-                decode_node<LEV - 1, NLOG, FAST, KEEP>(d, nc, maskv, pidv, chan_lane, cidx, (int)h, rc);
+                decode_node<LEV - 1, NLOG, FAST>(d, nc, maskv, pidv, chan_lane, cidx, (int)h, rc);
             }
         }
     }
     d.template combine<LEV>(plane);
 }
 
-template <typename T, int NLOG, bool FAST, bool KEEP>
-__global__ void __launch_bounds__(64, KEEP ? 3 : 4) sc_reg_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, NodeClasses nc,
+template <typename T, int NLOG, bool FAST>
+__global__ void __launch_bounds__(64, 4) sc_reg_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, NodeClasses nc,
                                                     const uint32_t *__restrict__ pid16, const uint32_t *__restrict__ Asl, uint32_t *__restrict__ info_hat, int64_t B,
                                                     int K, int Kw)
 {
@@ -251,7 +142,7 @@ __global__ void __launch_bounds__(64, KEEP ? 3 : 4) sc_reg_kernel(const T *__res
     const int lane = threadIdx.x;
     const int grp = lane >> 4;
     const int sub = lane & 15;
-    RegDec<T, NLOG, KEEP> d;
+    RegDec<T, NLOG> d;
     RowConst rc;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -268,7 +159,7 @@ __global__ void __launch_bounds__(64, KEEP ? 3 : 4) sc_reg_kernel(const T *__res
         const T *chan_lane = llr + fc * N + sub;
         d.ps0 = d.ps1 = 0;
         d.root = 0;
-        decode_node<NLOG, NLOG, FAST, KEEP>(d, nc, maskv, pidv, chan_lane, 0u, 0, rc);
+        decode_node<NLOG, NLOG, FAST>(d, nc, maskv, pidv, chan_lane, 0u, 0, rc);
 
         // u_hat = x_hat F^{(x)n} on the sliced layout: element k = sub + 16 j is bit j of lane sub.
         ps_t u = d.root;
@@ -360,28 +251,27 @@ bool sc_reg_supported(const polar_code *c, int dtype, const void *u_hat, const v
     return true;
 }
 
-template <typename T, int NLOG, bool FAST, bool KEEP = false>
-static int launch_reg_t(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B)
+template <typename T, int NLOG, bool FAST> static int launch_reg_t(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B)
 {
-    if constexpr (NLOG == 10 && FAST && !KEEP) {
-        const char *e = getenv("POLAR_SC_KEEP");
-        if (e && e[0] == '1') return launch_reg_t<T, NLOG, FAST, true>(c, llr, info_hat, B);
-    }
     polar_ctx *ctx = c->ctx;
     const NodeClasses nc = classify_nodes(c, FAST);
-    auto kern = sc_reg_kernel<T, NLOG, FAST, KEEP>;
+    auto kern = sc_reg_kernel<T, NLOG, FAST>;
+    // POLAR_SC_LDSPAD (bytes of unused dynamic LDS per wavefront) lowers the occupancy for experiments
+    const char *pe = getenv("POLAR_SC_LDSPAD");
+    const size_t pad = pe ? (size_t)atoi(pe) : 0;
+    if (pad > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
     int occ = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, pad));
     if (occ < 1) occ = 1;
     int64_t need = (B + 3) / 4;
     int64_t grid = std::min<int64_t>(need, (int64_t)ctx->num_cus * occ * 8);
     LaunchTimer tm(ctx);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), 0, ctx->stream, (const T *)llr, (const uint32_t *)c->d_maskw, nc,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), pad, ctx->stream, (const T *)llr, (const uint32_t *)c->d_maskw, nc,
                        (const uint32_t *)c->d_pid16, (const uint32_t *)c->d_Asl, info_hat, B, c->K, c->Kw);
     HIP_TRY(hipGetLastError());
     float ms = tm.stop();
-    snprintf(c->last.kernel, sizeof(c->last.kernel), "sc_reg_kernel<%s,%d>%s%s", sizeof(T) == 4 ? "float" : "double", NLOG,
-             FAST ? "/fast" : "", KEEP ? "/keep" : "");
+    snprintf(c->last.kernel, sizeof(c->last.kernel), "sc_reg_kernel<%s,%d>%s", sizeof(T) == 4 ? "float" : "double", NLOG,
+             FAST ? "/fast" : "");
     c->last.lanes_per_frame = 16;
     c->last.lds_bytes_per_block = 512;
     c->last.block_threads = 64;

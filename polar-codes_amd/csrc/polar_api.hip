@@ -106,7 +106,7 @@ extern "C" int polar_ctx_enable_timing(polar_ctx *c, int on)
 
 // ---------------------------------------------------------------------------------------------- schedule
 // Depth-first walk of the code tree.  A node at `level` covers leaves [pos, pos + 2^level).
-static void walk(const uint8_t *mask, int level, int pos, int plane, bool fast, std::vector<uint32_t> &ops)
+static void walk(const uint8_t *mask, int level, int pos, int plane, bool fast, bool sub16, std::vector<uint32_t> &ops)
 {
     int w = 1 << level;
     int ninfo = 0;
@@ -123,19 +123,25 @@ static void walk(const uint8_t *mask, int level, int pos, int plane, bool fast, 
         ops.push_back(make_op(mask[pos] ? OP_LEAF_INFO : OP_LEAF_FROZEN, 0, plane, pos));
         return;
     }
+    if (sub16 && level == 4) {
+        uint32_t m16 = 0;
+        for (int i = 0; i < 16; i++) m16 |= (uint32_t)(mask[pos + i] ? 1 : 0) << i;
+        ops.push_back(make_op(OP_SUB16, level, plane, m16));
+        return;
+    }
     ops.push_back(make_op(OP_F, level, 0));
-    walk(mask, level - 1, pos, 0, fast, ops);
+    walk(mask, level - 1, pos, 0, fast, sub16, ops);
     ops.push_back(make_op(OP_G, level, 0));
-    walk(mask, level - 1, pos + w / 2, 1, fast, ops);
+    walk(mask, level - 1, pos + w / 2, 1, fast, sub16, ops);
     ops.push_back(make_op(OP_COMBINE, level, plane));
 }
 
-std::vector<uint32_t> build_schedule(const uint8_t *mask, int N, bool fast)
+std::vector<uint32_t> build_schedule(const uint8_t *mask, int N, bool fast, bool sub16)
 {
     std::vector<uint32_t> ops;
     int n = 0;
     while ((1 << n) < N) n++;
-    walk(mask, n, 0, 0, fast, ops);
+    walk(mask, n, 0, 0, fast, sub16 && n >= 5, ops);
     ops.push_back(make_op(OP_END, 0, 0));
     return ops;
 }
@@ -146,7 +152,7 @@ extern "C" int polar_schedule_build(const uint8_t *mask, int N, int fast, uint32
     ARG_TRY(N >= 2 && N <= 65536 && (N & (N - 1)) == 0, "N must be a power of two in [2, 65536]");
     std::vector<uint8_t> m(mask, mask + N);
     for (auto &v : m) v = v ? 1 : 0;
-    std::vector<uint32_t> ops = build_schedule(m.data(), N, fast != 0);
+    std::vector<uint32_t> ops = build_schedule(m.data(), N, (fast & 1) != 0, (fast & 2) != 0);
     if (out)
         for (size_t i = 0; i < ops.size() && (int)i < cap; i++) out[i] = ops[i];
     return (int)ops.size();
@@ -178,6 +184,8 @@ extern "C" int polar_code_create(polar_ctx *ctx, int N, const uint8_t *mask, pol
     c->Kw = std::max(1, (c->K + 31) / 32);
     c->sched[0] = build_schedule(c->mask.data(), N, false);
     c->sched[1] = build_schedule(c->mask.data(), N, true);
+    c->sched[2] = build_schedule(c->mask.data(), N, false, true);
+    c->sched[3] = build_schedule(c->mask.data(), N, true, true);
     std::vector<uint32_t> Asl;
     for (uint32_t pos : A) Asl.push_back(((pos & 15u) << 6) | (pos >> 4));
     std::vector<uint32_t> Asl8;
@@ -202,7 +210,8 @@ extern "C" int polar_code_create(polar_ctx *ctx, int N, const uint8_t *mask, pol
     };
     int rc;
     if ((rc = up(&c->d_maskw, maskw)) || (rc = up(&c->d_rank, rank)) || (rc = up(&c->d_A, A)) ||
-        (rc = up(&c->d_sched[0], c->sched[0])) || (rc = up(&c->d_sched[1], c->sched[1])) || (rc = up(&c->d_Asl, Asl)) || (rc = up(&c->d_Asl8, Asl8)) ||
+        (rc = up(&c->d_sched[0], c->sched[0])) || (rc = up(&c->d_sched[1], c->sched[1])) ||
+        (rc = up(&c->d_sched[2], c->sched[2])) || (rc = up(&c->d_sched[3], c->sched[3])) || (rc = up(&c->d_Asl, Asl)) || (rc = up(&c->d_Asl8, Asl8)) ||
         (rc = up(&c->d_pid16, pid16))) {
         polar_code_destroy(c);
         return rc;

@@ -39,6 +39,7 @@ enum : uint32_t {
     OP_R0 = 4,       // whole node frozen: partial sums are zero
     OP_R1 = 5,       // whole node information: partial sums = hard decisions of its LLRs
     OP_COMBINE = 6,  // node partial sums (xl ^ xr, xr) from its two children
+    OP_SUB16 = 7,    // a whole 16-leaf node decoded in registers; bits 12..27 = its rate profile (leaf i = bit i)
     OP_END = 15
 };
 static inline uint32_t make_op(uint32_t type, uint32_t level, uint32_t plane, uint32_t leaf = 0)
@@ -50,8 +51,8 @@ static inline uint32_t make_op(uint32_t type, uint32_t level, uint32_t plane, ui
 #define OP_PLANE(w) (((w) >> 9) & 1u)
 #define OP_LEAFIDX(w) ((w) >> 12)
 
-std::vector<uint32_t> build_schedule(const uint8_t *mask, int N, bool fast);
-std::vector<uint32_t> build_schedule_reg(const uint8_t *mask, int N, bool fast);
+// sub16: 16-leaf nodes become one OP_SUB16 each instead of their 61 leaf-level operations
+std::vector<uint32_t> build_schedule(const uint8_t *mask, int N, bool fast, bool sub16 = false);
 
 // ---- grow-only device buffer ------------------------------------------------------------------
 struct DevBuf {
@@ -79,7 +80,7 @@ struct polar_code {
     int N = 0, n = 0, K = 0;
     int Nw = 0, Kw = 0;  // words per frame (codeword / info)
     std::vector<uint8_t> mask;
-    std::vector<uint32_t> sched[4];  // 0 = plain, 1 = fast; 2 = fast, 3 = plain for the register kernel
+    std::vector<uint32_t> sched[4];  // 0 = plain, 1 = fast; 2 = plain, 3 = fast with 16-leaf nodes as single operations
     // device tables
     uint32_t *d_maskw = nullptr;   // Nw words
     uint32_t *d_rank = nullptr;    // Nw words: info bits before word w

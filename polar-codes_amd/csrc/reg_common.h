@@ -57,3 +57,104 @@ __device__ __forceinline__ double f_fast(double a, double b) { return f_minsum(a
 __device__ __forceinline__ float g_fast(float a, float b, uint32_t bit) { return b + __uint_as_float(__float_as_uint(a) ^ (bit << 31)); }
 __device__ __forceinline__ double g_fast(double a, double b, uint32_t bit) { return g_apply(a, b, bit); }
 
+// ---- 16-leaf nodes decoded in registers by one DPP row ---------------------------------------------
+// Lane constants of the replicated butterfly: for period P, lanes whose element index is in the upper half.
+struct RowConst {
+    uint32_t lowmask[4];  // P = 16, 8, 4, 2: all-ones when (sub & P/2) == 0
+    bool up[4];
+};
+
+// Decodes a node of P leaves whose P LLRs are replicated with period P over the row.
+// mask: P bits (wave-uniform), bit i = leaf i carries information.  Returns the node's partial-sum bit of
+// element (sub mod P) as an integer 0/1.  SHORT enables the rate-0 / rate-1 short-cuts at P = 8 and 4
+// (same decisions).
+template <int P, bool SHORT, typename T> __device__ __forceinline__ uint32_t sub_node(T v, uint32_t mask, const RowConst &rc)
+{
+    if constexpr (P == 1) {
+        const uint32_t neg = pin(v < (T)0 ? 1u : 0u);
+        return neg & mask;  // mask is the single (uniform) info bit
+    } else {
+        constexpr uint32_t FULL = (1u << P) - 1u, HALF = (1u << (P / 2)) - 1u;
+        constexpr int I = P == 16 ? 0 : P == 8 ? 1 : P == 4 ? 2 : 3;
+        if (SHORT && P < 16) {
+            if (mask == 0u) return 0u;
+            if (mask == FULL) return pin(v < (T)0 ? 1u : 0u);
+            // only the last leaf carries information: every left child is all-frozen, so the node reduces to
+            // the g-chain with zero partial sums, hi + lo level by level, and one decision shared by all leaves
+            if (mask == (1u << (P - 1))) {
+                T s = v + partner<P>(v);
+                if constexpr (P >= 4) s = s + partner<P / 2>(s);
+                if constexpr (P >= 8) s = s + partner<P / 4>(s);
+                return pin(s < (T)0 ? 1u : 0u);
+            }
+            if constexpr (P == 4) {
+                // leaves 2, 3: the left pair is frozen, the right pair is decided by sign
+                if (mask == 0xCu) {
+                    const T s = v + partner<4>(v);
+                    return pin(s < (T)0 ? 1u : 0u);
+                }
+                // leaves 1, 2, 3: left pair = one decision on the sum of the two f outputs, right pair by sign
+                if (mask == 0xEu) {
+                    const T o4 = partner<4>(v);
+                    const T vl4 = f_fast(v, o4);
+                    const T sl = vl4 + partner<2>(vl4);
+                    const uint32_t xl4 = pin(sl < (T)0 ? 1u : 0u);
+                    const T lo4 = rc.up[I] ? o4 : v, hi4 = rc.up[I] ? v : o4;
+                    const T vr4 = g_fast(lo4, hi4, xl4);
+                    const uint32_t xr4 = pin(vr4 < (T)0 ? 1u : 0u);
+                    return xr4 ^ (xl4 & rc.lowmask[I]);
+                }
+            }
+        }
+        const T o = partner<P>(v);
+        const T lo = rc.up[I] ? o : v, hi = rc.up[I] ? v : o;
+        const T vl = f_fast(v, o);
+        const uint32_t xl = sub_node<P / 2, SHORT>(vl, mask & HALF, rc);
+        const T vr = g_fast(lo, hi, xl);
+        const uint32_t xr = sub_node<P / 2, SHORT>(vr, (mask >> (P / 2)) & HALF, rc);
+        return xr ^ (xl & rc.lowmask[I]);
+    }
+}
+
+// The same decoder with the rate profile of the node known at compile time: no branch is left.
+template <int P, uint32_t MASK, typename T> __device__ __forceinline__ uint32_t sub_node_c(T v, const RowConst &rc)
+{
+    constexpr uint32_t FULL = (P >= 32) ? 0xFFFFFFFFu : ((1u << P) - 1u), HALF = (1u << (P / 2)) - 1u;
+    constexpr int I = P == 16 ? 0 : P == 8 ? 1 : P == 4 ? 2 : 3;
+    if constexpr (MASK == 0u) {
+        return 0u;
+    } else if constexpr (MASK == FULL) {
+        return pin(v < (T)0 ? 1u : 0u);
+    } else if constexpr (MASK == (1u << (P - 1))) {
+        T s = v + partner<P>(v);
+        if constexpr (P >= 4) s = s + partner<P / 2>(s);
+        if constexpr (P >= 8) s = s + partner<P / 4>(s);
+        if constexpr (P >= 16) s = s + partner<P / 8>(s);
+        return pin(s < (T)0 ? 1u : 0u);
+    } else {
+        constexpr uint32_t ML = MASK & HALF, MR = (MASK >> (P / 2)) & HALF;
+        const T o = partner<P>(v);
+        if constexpr (ML == 0u) {
+            // frozen left half: its partial sums are zero, the right half sees hi + lo
+            const T vr = v + o;
+            return sub_node_c<P / 2, MR>(vr, rc);
+        } else {
+            const T lo = rc.up[I] ? o : v, hi = rc.up[I] ? v : o;
+            const T vl = f_fast(v, o);
+            const uint32_t xl = sub_node_c<P / 2, ML>(vl, rc);
+            const T vr = g_fast(lo, hi, xl);
+            const uint32_t xr = sub_node_c<P / 2, MR>(vr, rc);
+            return xr ^ (xl & rc.lowmask[I]);
+        }
+    }
+}
+
+// The 25 rate profiles of a 16-leaf node that respect the partial order of the bit channels (an information
+// position implies every position reachable by setting a bit or moving a one towards the MSB); a code built from
+// any reliability ordering only has these, all-frozen and all-information.  Leaf i = bit i.
+#define POLAR_PROFILES16(X)                                                                                         \
+    X(1, 0x8000u) X(2, 0xC000u) X(3, 0xE000u) X(4, 0xE800u) X(5, 0xE880u) X(6, 0xF000u) X(7, 0xF800u) X(8, 0xF880u)   \
+    X(9, 0xFC00u) X(10, 0xFC80u) X(11, 0xFCC0u) X(12, 0xFE00u) X(13, 0xFE80u) X(14, 0xFEC0u) X(15, 0xFEE0u)          \
+    X(16, 0xFEE8u) X(17, 0xFF00u) X(18, 0xFF80u) X(19, 0xFFC0u) X(20, 0xFFE0u) X(21, 0xFFE8u) X(22, 0xFFF0u)         \
+    X(23, 0xFFF8u) X(24, 0xFFFCu) X(25, 0xFFFEu)
+

@@ -2,7 +2,18 @@
 compiler without a GPU.  Mirrors the operation semantics of the SC kernel."""
 import numpy as np
 
-OP_F, OP_G, OP_LEAF_INFO, OP_LEAF_FROZEN, OP_R0, OP_R1, OP_COMBINE, OP_END = 0, 1, 2, 3, 4, 5, 6, 15
+OP_F, OP_G, OP_LEAF_INFO, OP_LEAF_FROZEN, OP_R0, OP_R1, OP_COMBINE, OP_SUB16, OP_END = 0, 1, 2, 3, 4, 5, 6, 7, 15
+
+
+def sc_node(llr, mask):
+    """Partial sums of a node by plain recursive SC (f = min-sum, g, combine)."""
+    if llr.size == 1:
+        return np.array([1 if (mask[0] and llr[0] < 0) else 0], dtype=np.uint8)
+    h = llr.size // 2
+    a, b = llr[:h], llr[h:]
+    xl = sc_node((np.sign(a) * np.sign(b) * np.minimum(np.abs(a), np.abs(b))).astype(llr.dtype), mask[:h])
+    xr = sc_node(np.where(xl == 1, b - a, b + a).astype(llr.dtype), mask[h:])
+    return np.concatenate([xl ^ xr, xr])
 
 
 def decode_op(w):
@@ -33,6 +44,8 @@ def run_schedule(ops, llr, N):
             v = lv[0][0]
             dec_llr[leaf] = v
             ps[plane][0] = np.array([1 if (t == OP_LEAF_INFO and v < 0) else 0], dtype=np.uint8)
+        elif t == OP_SUB16:
+            ps[plane][4] = sc_node(lv[4], [(leaf >> i) & 1 for i in range(16)])
         elif t == OP_R0:
             ps[plane][lev] = np.zeros(1 << lev, dtype=np.uint8)
         elif t == OP_R1:

@@ -75,6 +75,10 @@ def test_schedules_decode_like_the_oracle(N, K, cons):
         assert d1.tobytes() == dl.tobytes()  # every leaf visited, same arithmetic
         u2, _ = run_schedule(fast, llr, N)
         assert np.array_equal(u2, uh)  # pruned schedule: same decisions
+        for f in (False, True):  # 16-leaf nodes as single operations
+            ops16 = _native.schedule_build(mask, f, sub16=True)
+            assert len(ops16) < len(fast if f else plain) or N < 32
+            assert np.array_equal(run_schedule(ops16, llr, N)[0], uh)
 
 
 def test_schedule_edge_profiles():
