@@ -15,6 +15,7 @@
 #include <algorithm>
 
 #include "decode_common.h"
+#include "reg_common.h"
 #include "polar_internal.h"
 
 template <typename T> struct PBFParams {
@@ -22,7 +23,7 @@ template <typename T> struct PBFParams {
     const uint32_t *rows;                 // frame index of work item w, or NULL for w itself
     const unsigned long long *nrows_dev;  // number of work items when rows != NULL
     unsigned long long *work;             // atomic work counter (zero at launch)
-    const uint32_t *ops;                  // every-leaf schedule
+    const uint32_t *ops;                  // every-leaf schedule (16-leaf nodes as single operations when N >= 32)
     const uint32_t *A;
     const uint32_t *crcS;                 // NULL: no CRC test (flip-list mode)
     const int32_t *S0;                    // level-0 candidates (critical set)
@@ -59,6 +60,12 @@ template <typename T> __global__ void __launch_bounds__(64) pbf_decode_kernel(PB
     uint32_t *iw = p1 + 2 * Nw;                                // Kw: information words of the last tested run
     uint32_t *misc = iw + p.Kw;                                // 1: work item broadcast
     uint16_t *order = reinterpret_cast<uint16_t *>(misc + 1);  // 3 x maxS: ranked candidates per level
+    RowConst rc;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        rc.up[i] = (lane & (8 >> i)) != 0;
+        rc.lowmask[i] = rc.up[i] ? 0u : 0xFFFFFFFFu;
+    }
 
     for (;;) {
         if (lane == 0) misc[0] = (uint32_t)atomicAdd(p.work, 1ull);
@@ -72,7 +79,11 @@ template <typename T> __global__ void __launch_bounds__(64) pbf_decode_kernel(PB
 
         // one SC run with decisions inverted at fl0..fl2; `tested`: extract the information word and test the CRC
         auto run = [&](int fl0, int fl1, int fl2, bool tested) -> bool {
+            fl0 = __builtin_amdgcn_readfirstlane(fl0);
+            fl1 = __builtin_amdgcn_readfirstlane(fl1);
+            fl2 = __builtin_amdgcn_readfirstlane(fl2);
             uint32_t nar0 = 0, nar1 = 0;
+            int blk = 0;  // 16-leaf nodes come in code order
             uint32_t next_op = ops[0];
             for (int pc = 0;; pc++) {
                 const uint32_t op = next_op;
@@ -116,6 +127,16 @@ template <typename T> __global__ void __launch_bounds__(64) pbf_decode_kernel(PB
                     if (plane) nar1 = (nar1 & ~2u) | (bit << 1);
                     else nar0 = (nar0 & ~2u) | (bit << 1);
                     if (lane == 0) dl[i] = v;
+                    break;
+                }
+                case OP_SUB16: {
+                    // one LLR per lane of a 16-lane row (the four rows do the same work); lane e ends up with bit e
+                    const T v = lv[16 + (lane & 15)];
+                    const uint32_t x = sub_node_flip<16, 0>(v, OP_LEAFIDX(op) & 0xFFFFu, rc, 16 * blk, fl0, fl1, fl2, dl, lane == 0);
+                    blk++;
+                    const uint32_t bits = (uint32_t)__ballot(x != 0u) & 0xFFFFu;
+                    if (plane) nar1 = (nar1 & 0x0000FFFFu) | (bits << 16);
+                    else nar0 = (nar0 & 0x0000FFFFu) | (bits << 16);
                     break;
                 }
                 case OP_COMBINE: {
@@ -349,7 +370,7 @@ static int launch_pbf_t(polar_code *c, const void *llr, const uint32_t *rows, co
     if (occ < 1) occ = 1;
     int64_t grid = std::min<int64_t>(B, (int64_t)ctx->num_cus * occ);
     LaunchTimer tm(ctx);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, ctx->stream, p, (const uint32_t *)c->d_sched[0]);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, ctx->stream, p, (const uint32_t *)c->d_sched[c->n >= 5 ? 2 : 0]);
     HIP_TRY(hipGetLastError());
     float ms = tm.stop();
     snprintf(c->last.kernel, sizeof(c->last.kernel), "pbf_decode_kernel<%s>/T%d", sizeof(T) == 4 ? "float" : "double", max_level);

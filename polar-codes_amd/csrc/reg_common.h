@@ -158,3 +158,28 @@ template <int P, uint32_t MASK, typename T> __device__ __forceinline__ uint32_t 
     X(16, 0xFEE8u) X(17, 0xFF00u) X(18, 0xFF80u) X(19, 0xFFC0u) X(20, 0xFFE0u) X(21, 0xFFE8u) X(22, 0xFFF0u)         \
     X(23, 0xFFF8u) X(24, 0xFFFCu) X(25, 0xFFFEu)
 
+// The 16-leaf decoder for the flip search: every leaf is visited (no short-cuts), its decision LLR is recorded
+// in dl[pos + leaf] and its decision is inverted when the leaf is one of the (wave-uniform) positions fl0..fl2.
+// OFF = index of the node's first leaf inside the 16-leaf block that starts at code position pos.
+template <int P, int OFF, typename T>
+__device__ __forceinline__ uint32_t sub_node_flip(T v, uint32_t mask, const RowConst &rc, int pos, int fl0, int fl1, int fl2, T *dl,
+                                                  bool writer)
+{
+    if constexpr (P == 1) {
+        const int i = pos + OFF;
+        uint32_t bit = pin(v < (T)0 ? 1u : 0u) & mask;
+        if (i == fl0 || i == fl1 || i == fl2) bit ^= 1u;
+        if (writer) dl[i] = v;
+        return bit;
+    } else {
+        constexpr uint32_t HALF = (1u << (P / 2)) - 1u;
+        constexpr int I = P == 16 ? 0 : P == 8 ? 1 : P == 4 ? 2 : 3;
+        const T o = partner<P>(v);
+        const T lo = rc.up[I] ? o : v, hi = rc.up[I] ? v : o;
+        const T vl = f_fast(v, o);
+        const uint32_t xl = sub_node_flip<P / 2, OFF>(vl, mask & HALF, rc, pos, fl0, fl1, fl2, dl, writer);
+        const T vr = g_fast(lo, hi, xl);
+        const uint32_t xr = sub_node_flip<P / 2, OFF + P / 2>(vr, (mask >> (P / 2)) & HALF, rc, pos, fl0, fl1, fl2, dl, writer);
+        return xr ^ (xl & rc.lowmask[I]);
+    }
+}
