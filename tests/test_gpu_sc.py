@@ -176,3 +176,33 @@ def test_sc_register_and_lds_kernels_agree(monkeypatch):
     b, _, _ = pc.native.sc_decode(llr, fast=True)
     assert pc.native.last_launch()["kernel"].startswith("sc_decode_kernel")
     assert np.array_equal(a, b)
+
+
+PROFILES16 = [0x8000, 0xC000, 0xE000, 0xE800, 0xE880, 0xF000, 0xF800, 0xF880, 0xFC00, 0xFC80, 0xFCC0, 0xFE00, 0xFE80, 0xFEC0,
+              0xFEE0, 0xFEE8, 0xFF00, 0xFF80, 0xFFC0, 0xFFE0, 0xFFE8, 0xFFF0, 0xFFF8, 0xFFFC, 0xFFFE]
+
+
+def test_sc_every_compiled_16_leaf_profile(monkeypatch):
+    """A rate profile whose 16-leaf nodes run through all 25 profiles the register kernel has compiled code for,
+    the all-frozen / all-information ones and some it has not: register kernel (fp32), and the LDS-staged kernel
+    with its in-register 16-leaf operation (fp32 and fp64), against the oracle."""
+    rs = np.random.RandomState(16)
+    blocks = PROFILES16 + [0x0000, 0xFFFF, 0x0001, 0x5555, 0x8001, 0x00FF, 0x7FFE] + [int(v) for v in rs.randint(0, 1 << 16, size=32)]
+    blocks = [blocks[i] for i in rs.permutation(len(blocks))]
+    mask = np.array([(m >> i) & 1 for m in blocks for i in range(16)], dtype=int)
+    N = mask.size
+    assert N == 1024
+    code = _native.Code(_native.default_ctx(), mask)
+    llr64 = rs.standard_normal((37, N)) * 2.5 + 0.7
+    for dtype in (np.float32, np.float64):
+        llr = llr64.astype(dtype)
+        ref_uh = np.stack([oracle.sc_decode(llr[b], mask) for b in range(llr.shape[0])])
+        ref = ref_uh[:, mask == 1]
+        for fast in (True, False):
+            info, uh, _ = code.sc_decode(llr, want_uhat=True, fast=fast)      # LDS-staged kernel, no decision LLRs
+            assert code.last_launch()["kernel"].startswith("sc_decode_kernel")
+            assert np.array_equal(uh, ref_uh) and np.array_equal(info, ref), (dtype, fast)
+            if dtype == np.float32:
+                info, _, _ = code.sc_decode(llr, fast=fast)
+                assert code.last_launch()["kernel"].startswith("sc_reg_kernel")
+                assert np.array_equal(info, ref), fast
