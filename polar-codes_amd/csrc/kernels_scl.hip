@@ -10,6 +10,10 @@
 // (pointer rows, the word of narrow partial sums, the metric).  Right-child ("plane 1") partial sums
 // are produced and consumed between two leaf decisions and stay with the list position.
 //
+// The widest stored level is n-2: the N/2 LLRs of level n-1 are not kept per path but recomputed from the
+// channel LLRs (and, in the right half of the tree, the path's left-half partial sums) by the two
+// operations that read them, which halves the LDS per wavefront and doubles the lists in flight per CU.
+//
 // Path metric (maximised): PM += 1 - log2(1 + 2^(-L/ln2 * (-1)^u)), evaluated in that order.  Below
 // saturation the list grows as originals ++ copies; at saturation the 2L candidates are ordered
 // copies(u=1) ++ originals(u=0), ranked by (metric descending, candidate position ascending) -- the
@@ -95,6 +99,7 @@ __global__ void __launch_bounds__(64) scl_decode_kernel(SCLParams<T> p, const ui
     uint32_t *p0_all = reinterpret_cast<uint32_t *>(smem + (size_t)L * p.slot_stride);
     uint32_t *p1_all = p0_all + (size_t)L * 2 * Nw;
     uint32_t *surv = p1_all + (size_t)L * 2 * Nw;
+    // slot s holds levels 0 .. n-2 of one path: level l (2^l values) at element offset 2^l
     auto tree = [&](uint32_t slot) { return reinterpret_cast<T *>(smem + (size_t)slot * p.slot_stride); };
     auto pl0 = [&](uint32_t slot) { return p0_all + (size_t)slot * 2 * Nw; };
     uint32_t *my_p1 = p1_all + (size_t)grp * 2 * Nw;
@@ -105,6 +110,17 @@ __global__ void __launch_bounds__(64) scl_decode_kernel(SCLParams<T> p, const ui
         uint32_t nar0 = 0, nar1 = 0;
         T pm = (T)0;
         int Lcur = 1;
+        bool right_half = false;  // which child of the root is being decoded
+        // LLR k of level n-1 for this path: f of the channel pair in the left half, g with the path's left-half
+        // partial sum in the right half
+        auto top = [&](int k) -> T {
+            const T a = chan[k], b = chan[k + (N >> 1)];
+            if (!right_half) return f_minsum(a, b);
+            uint32_t bit;
+            if (n - 1 >= 5) bit = (pl0(ptr_get(ptrP, n - 1))[(1 << (n - 6)) + (k >> 5)] >> (k & 31)) & 1u;
+            else bit = (nar0 >> ((N >> 1) + k)) & 1u;
+            return bit ? b - a : b + a;
+        };
 
         uint32_t next_op = ops[0];
         for (int pc = 0;; pc++) {
@@ -118,17 +134,50 @@ __global__ void __launch_bounds__(64) scl_decode_kernel(SCLParams<T> p, const ui
             switch (type) {
             case OP_F: {
                 const int w = 1 << (lev - 1);
-                const T *src = (lev == n) ? chan : tree(ptr_get(ptrL, lev)) + (1 << lev);
+                if (lev == n && n >= 2) {
+                    right_half = false;  // level n-1 is virtual
+                    break;
+                }
                 T *dst = tree(grp) + w;
-                if (act)
-                    for (int k = sub; k < w; k += G) dst[k] = f_minsum(src[k], src[k + w]);
+                if (lev == n - 1) {
+                    if (act)
+                        for (int k = sub; k < w; k += G) dst[k] = f_minsum(top(k), top(k + w));
+                } else {
+                    const T *src = (lev == n) ? chan : tree(ptr_get(ptrL, lev)) + (1 << lev);
+                    if (act)
+                        for (int k = sub; k < w; k += G) dst[k] = f_minsum(src[k], src[k + w]);
+                }
                 ptrL = ptr_set(ptrL, lev - 1, grp);
                 break;
             }
             case OP_G: {
                 const int w = 1 << (lev - 1);
-                const T *src = (lev == n) ? chan : tree(ptr_get(ptrL, lev)) + (1 << lev);
+                if (lev == n && n >= 2) {
+                    right_half = true;  // level n-1 is virtual
+                    break;
+                }
                 T *dst = tree(grp) + w;
+                if (lev == n - 1) {
+                    if (act) {
+                        if (lev - 1 >= 5) {
+                            const uint32_t *bits = pl0(ptr_get(ptrP, lev - 1)) + (1 << (lev - 6));
+                            for (int k = sub; k < w; k += G) {
+                                T a = top(k), b = top(k + w);
+                                uint32_t bit = (bits[k >> 5] >> (k & 31)) & 1u;
+                                dst[k] = bit ? b - a : b + a;
+                            }
+                        } else {
+                            for (int k = sub; k < w; k += G) {
+                                T a = top(k), b = top(k + w);
+                                uint32_t bit = (nar0 >> (w + k)) & 1u;
+                                dst[k] = bit ? b - a : b + a;
+                            }
+                        }
+                    }
+                    ptrL = ptr_set(ptrL, lev - 1, grp);
+                    break;
+                }
+                const T *src = (lev == n) ? chan : tree(ptr_get(ptrL, lev)) + (1 << lev);
                 if (act) {
                     if (lev - 1 >= 5) {
                         const uint32_t *bits = pl0(ptr_get(ptrP, lev - 1)) + (1 << (lev - 6));
@@ -348,8 +397,8 @@ static int launch_scl_t(polar_code *c, const void *llr, uint32_t *info_hat, doub
     p.Nw = c->Nw;
     p.K = c->K;
     p.Kw = c->Kw;
-    // slot stride: the tree, rounded to 256 B, skewed by one group's worth of banks
-    size_t stride = (((size_t)c->N * sizeof(T)) + 255) & ~(size_t)255;
+    // slot stride: the tree up to level n-2 (N/2 values), rounded to 256 B, skewed by one group's worth of banks
+    size_t stride = (((size_t)std::max(c->N / 2, 2) * sizeof(T)) + 255) & ~(size_t)255;
     if (L > 1) stride += ((size_t)G * sizeof(T)) % 256;
     p.slot_stride = (int)stride;
     size_t lds = stride * L + (size_t)2 * L * 2 * c->Nw * 4 + 32 * 4;
