@@ -6,7 +6,9 @@
 //   - the LLR tree below the channel level: level l (2^l values) at element offset 2^l,
 //   - two planes of bit-packed partial sums: level l >= 5 at word offset 2^(l-5); the five narrow
 //     levels (1..16 bits) share one 32-bit register per plane (level l at bit offset 2^l).
-// The channel LLRs are read straight from global memory by the two top-level operations.
+// The channel LLRs are read straight from global memory.  For N >= 128 level n-1 is not stored either: the
+// operations that read it recompute its values from the channel pair (and the left half's partial sums),
+// which halves the LDS per frame.
 // Lane `sub` of a group handles elements sub, sub+G, ... so LDS accesses of a group are contiguous.
 // Workgroups are single wavefronts: no workgroup barrier is ever needed.
 #include <stdio.h>
@@ -28,6 +30,7 @@ template <typename T> struct SCParams {
     int64_t B;
     int N, n, Nw, K, Kw;
     int stride_bytes;  // LDS bytes between the frames of one wavefront
+    int tree_bytes;    // LDS bytes of one frame's stored LLR levels
 };
 
 template <typename T, int G> __global__ void __launch_bounds__(64) sc_decode_kernel(SCParams<T> p)
@@ -39,7 +42,7 @@ template <typename T, int G> __global__ void __launch_bounds__(64) sc_decode_ker
     const int sub = lane % G;
     unsigned char *base = smem + (size_t)grp * p.stride_bytes;
     T *lv = reinterpret_cast<T *>(base);
-    uint32_t *p0 = reinterpret_cast<uint32_t *>(base + (size_t)p.N * sizeof(T));
+    uint32_t *p0 = reinterpret_cast<uint32_t *>(base + (size_t)p.tree_bytes);
     uint32_t *p1 = p0 + 2 * p.Nw;
     const int N = p.N, n = p.n, Nw = p.Nw;
     RowConst rc;  // position of this lane in its 16-lane row, for the in-register 16-leaf nodes
@@ -55,6 +58,14 @@ template <typename T, int G> __global__ void __launch_bounds__(64) sc_decode_ker
         const int64_t fc = active ? f : p.B - 1;  // idle groups shadow the last frame, stores masked
         const T *chan = p.llr + fc * N;
         uint32_t nar0 = 0, nar1 = 0;
+        const bool virt = n >= 7;  // level n-1 is virtual (its own and its children's partial sums are then whole words)
+        bool right_half = false;
+        auto top = [&](int k) -> T {
+            const T a = chan[k], b = chan[k + (N >> 1)];
+            if (!right_half) return f_minsum(a, b);
+            const uint32_t bit = (p0[(1 << (n - 6)) + (k >> 5)] >> (k & 31)) & 1u;
+            return bit ? b - a : b + a;
+        };
 
         for (int pc = 0;; pc++) {
             const uint32_t op = p.ops[pc];
@@ -65,12 +76,33 @@ template <typename T, int G> __global__ void __launch_bounds__(64) sc_decode_ker
             switch (type) {
             case OP_F: {
                 const int w = 1 << (lev - 1);
+                if (virt && lev == n) {
+                    right_half = false;
+                    break;
+                }
+                if (virt && lev == n - 1) {
+                    for (int k = sub; k < w; k += G) lv[w + k] = f_minsum(top(k), top(k + w));
+                    break;
+                }
                 const T *src = (lev == n) ? chan : lv + (1 << lev);
                 for (int k = sub; k < w; k += G) lv[w + k] = f_minsum(src[k], src[k + w]);
                 break;
             }
             case OP_G: {
                 const int w = 1 << (lev - 1);
+                if (virt && lev == n) {
+                    right_half = true;
+                    break;
+                }
+                if (virt && lev == n - 1) {
+                    const uint32_t *bits = p0 + (1 << (lev - 6));
+                    for (int k = sub; k < w; k += G) {
+                        T a = top(k), b = top(k + w);
+                        uint32_t bit = (bits[k >> 5] >> (k & 31)) & 1u;
+                        lv[w + k] = bit ? b - a : b + a;
+                    }
+                    break;
+                }
                 const T *src = (lev == n) ? chan : lv + (1 << lev);
                 if (lev - 1 >= 5) {
                     const uint32_t *bits = p0 + (1 << (lev - 6));
@@ -124,7 +156,14 @@ template <typename T, int G> __global__ void __launch_bounds__(64) sc_decode_ker
             case OP_R1: {
                 const int w = 1 << lev;
                 const T *src = (lev == n) ? chan : lv + w;
-                if (lev >= 5) {
+                if (virt && lev == n - 1) {
+                    uint32_t *dst = (plane ? p1 : p0) + (1 << (lev - 5));
+                    pack_bits_group<G>(
+                        w, sub, grp, [&](int k) { return top(k) < (T)0; },
+                        [&](int wi, uint32_t v) {
+                            if (sub == 0) dst[wi] = v;
+                        });
+                } else if (lev >= 5) {
                     uint32_t *dst = (plane ? p1 : p0) + (1 << (lev - 5));
                     pack_bits_group<G>(
                         w, sub, grp, [&](int k) { return src[k] < (T)0; },
@@ -244,7 +283,8 @@ static int launch_sc_t(polar_code *c, const void *llr, uint32_t *info_hat, uint3
     p.Kw = c->Kw;
     // frame stride: tree + two planes of 2*Nw words, rounded to 256 B, then skewed by one group's
     // worth of banks so that the groups of a wavefront do not collide on LDS banks
-    size_t raw = (size_t)c->N * sizeof(T) + (size_t)4 * c->Nw * 4;
+    p.tree_bytes = (int)((size_t)(c->n >= 7 ? c->N / 2 : c->N) * sizeof(T));
+    size_t raw = (size_t)p.tree_bytes + (size_t)4 * c->Nw * 4;
     size_t stride = (raw + 255) & ~(size_t)255;
     if (FPW > 1) stride += ((size_t)G * sizeof(T)) % 256;
     p.stride_bytes = (int)stride;
