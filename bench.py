@@ -119,6 +119,9 @@ def main():
     mask = pcf.degaBuild(N, K, 2.0)
     ctx = _native.default_ctx(local)
     code = _native.Code(ctx, mask)
+    t0 = time.perf_counter()
+    code.specialize()  # per-code set-up: the SC decoder unrolled for this rate profile, built by the run-time compiler
+    specialize_s = time.perf_counter() - t0
     ch = Channel("BPSK", a.snr, "SNRb", K / N)
     B = a.frames
     seed = 2024
@@ -223,6 +226,7 @@ def main():
             "ber": cnt[2] / max(cnt[0] * K, 1),
             "counters": cnt,
             "input_gen_s": gen_s,
+        "specialize_s": specialize_s,
             "scl8": scl,
             "roofline": {
                 "bound": "hbm",

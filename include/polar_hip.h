@@ -73,6 +73,15 @@ int polar_code_n(const polar_code *code);
 int polar_code_k(const polar_code *code);
 /* Number of decoder schedule operations: which = 0 plain SC (visits every leaf), 1 = fast SC. */
 int polar_code_schedule_len(const polar_code *code, int which);
+/* Compiles, with the HIP run-time compiler, an SC decoder specialised for this code's rate profile (an
+ * "unrolled" decoder: the whole tree walk becomes straight-line code) and uses it from then on for
+ * polar_sc_decode* / polar_mc_run calls with POLAR_SC_FAST, fp32 LLRs and information-bit output only.
+ * Same decisions as the generic kernels.  32 <= N <= 1024, 0 < K < N.  Takes seconds; meant for long runs
+ * over one code, like the per-code set-up of PolarCode.__init__ (cn/polarCode.py:116-157).  No counterpart
+ * in the reference.  polar_static_compile_check is the host-only part (no GPU needed): it compiles for `arch`
+ * (e.g. "gfx950") and returns the size of the code object in bytes, or a negative error code. */
+int polar_code_specialize(polar_code *code);
+int polar_static_compile_check(const uint8_t *mask, int N, const char *arch);
 /* CRC of CRC-aided list decoding: pcode.crcPoly / pcode.crcWidth (cn/simulator.py:84-85) as consumed by
  * pcf.crcEncode (cn/functions.py:567-583).  crc_poly holds the generator polynomial with its leading term
  * (0x107 = x^8+x^2+x+1); the width is its degree, 1..32 and at most K.  0 removes the CRC.  The K information

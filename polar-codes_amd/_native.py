@@ -46,6 +46,8 @@ SIGNATURES = {
     "polar_code_n": (_i, [_vp]),
     "polar_code_k": (_i, [_vp]),
     "polar_code_schedule_len": (_i, [_vp, _i]),
+    "polar_code_specialize": (_i, [_vp]),
+    "polar_static_compile_check": (_i, [_vp, _i, C.c_char_p]),
     "polar_code_set_crc": (_i, [_vp, _u64]),
     "polar_code_crc_width": (_i, [_vp]),
     "polar_schedule_build": (_i, [_vp, _i, _i, _vp, _i]),
@@ -168,6 +170,11 @@ class Code:
 
     def schedule_len(self, fast):
         return lib().polar_code_schedule_len(self._h, 1 if fast else 0)
+
+    def specialize(self):
+        """Compile (hiprtc, a few seconds) the SC decoder unrolled for this rate profile; fast fp32 SC decoding
+        of this code uses it from then on."""
+        _check(lib().polar_code_specialize(self._h))
 
     def set_crc(self, crc_poly):
         """Attach (or with 0 remove) the CRC generator polynomial, leading term included (0x107 = CRC-8)."""
@@ -325,6 +332,15 @@ def schedule_build(mask, fast, sub16=False):
     out = np.empty(n, dtype=np.uint32)
     _check(min(0, lib().polar_schedule_build(m.ctypes.data, m.size, fast, out.ctypes.data, n)))
     return out
+
+
+def static_compile_check(mask, arch="gfx950"):
+    """Host only: run the run-time compiler on the decoder specialised for `mask`; returns the code size."""
+    m = np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8)
+    n = lib().polar_static_compile_check(m.ctypes.data, m.size, arch.encode())
+    if n < 0:
+        _check(n)
+    return n
 
 
 def critical_set(mask, after=-1):

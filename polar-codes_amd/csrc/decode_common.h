@@ -1,7 +1,16 @@
 // Device helpers shared by the SC and SCL decoder kernels.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#else  // the run-time compiler brings its own HIP declarations but no <stdint.h>
+typedef unsigned char uint8_t;
+typedef unsigned short uint16_t;
+typedef int int32_t;
+typedef unsigned int uint32_t;
+typedef long int64_t;
+typedef unsigned long uint64_t;
+#endif
 
 __device__ __forceinline__ void wave_sync()
 {

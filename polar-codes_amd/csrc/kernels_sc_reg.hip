@@ -20,66 +20,8 @@
 
 #include "decode_common.h"
 #include "reg_common.h"
+#include "kernels_sc_static.h"
 #include "polar_internal.h"
-
-typedef uint64_t ps_t;
-
-template <typename T, int NLOG> struct RegDec {
-    static constexpr int S = 1 << (NLOG - 4);  // slice length per lane
-    T R[S];                                    // level l (4 <= l < NLOG): 2^(l-4) values at offset 2^(l-4)
-    ps_t ps0, ps1;                             // partial sums (plane 0 / 1), same offsets, one bit per value
-    ps_t root;
-
-    // f or g from level LEV to LEV-1 (5 <= LEV <= NLOG); the top level reads the channel from memory
-    template <int LEV, bool IS_G> __device__ __forceinline__ void step(const T *chan_lane)
-    {
-        constexpr int c = 1 << (LEV - 5);
-#pragma unroll
-        for (int j = 0; j < c; j++) {
-            T a, b;
-            if constexpr (LEV == NLOG) {
-                a = chan_lane[16 * j];
-                b = chan_lane[16 * (j + c)];
-            } else {
-                a = R[2 * c + j];
-                b = R[3 * c + j];
-            }
-            if constexpr (IS_G) R[c + j] = g_fast(a, b, (uint32_t)(ps0 >> (c + j)) & 1u);
-            else R[c + j] = f_fast(a, b);
-        }
-    }
-    template <int LEV> __device__ __forceinline__ void combine(int plane)
-    {
-        constexpr int c = 1 << (LEV - 5);
-        const ps_t m = (c >= 64) ? ~(ps_t)0 : (((ps_t)1 << c) - 1);
-        const ps_t xl = (ps0 >> c) & m, xr = (ps1 >> c) & m;
-        if constexpr (LEV == NLOG) {
-            root = (xl ^ xr) | (c >= 64 ? 0 : (xr << c));
-        } else {
-            const ps_t x = (xl ^ xr) | (xr << c);
-            const ps_t m2 = (((ps_t)1 << (2 * c)) - 1) << (2 * c);
-            if (plane) ps1 = (ps1 & ~m2) | (x << (2 * c));
-            else ps0 = (ps0 & ~m2) | (x << (2 * c));
-        }
-    }
-    template <int LEV> __device__ __forceinline__ void rate0(int plane)
-    {
-        constexpr int c = 1 << (LEV - 4);
-        const ps_t m2 = (((ps_t)1 << c) - 1) << c;
-        if (plane) ps1 &= ~m2;
-        else ps0 &= ~m2;
-    }
-    template <int LEV> __device__ __forceinline__ void rate1(int plane)
-    {
-        constexpr int c = 1 << (LEV - 4);
-        ps_t x = 0;
-#pragma unroll
-        for (int j = 0; j < c; j++) x |= (ps_t)(R[c + j] < (T)0 ? 1u : 0u) << j;
-        const ps_t m2 = (((ps_t)1 << c) - 1) << c;
-        if (plane) ps1 = (ps1 & ~m2) | (x << c);
-        else ps0 = (ps0 & ~m2) | (x << c);
-    }
-};
 
 // Node classes per tree level (bit i of level l = node i of that level, l = 4 .. 10 -> index l-4):
 // r0 = every leaf frozen, r1 = every leaf information.  In plain (non-fast) mode both are all zero.
@@ -161,52 +103,7 @@ __global__ void __launch_bounds__(64, 4) sc_reg_kernel(const T *__restrict__ llr
         d.root = 0;
         decode_node<NLOG, NLOG, FAST>(d, nc, maskv, pidv, chan_lane, 0u, 0, rc);
 
-        // u_hat = x_hat F^{(x)n} on the sliced layout: element k = sub + 16 j is bit j of lane sub.
-        ps_t u = d.root;
-        // stages 4 .. NLOG-1 pair (j, j + 2^(s-4)) inside a lane
-        if constexpr (NLOG > 4) u ^= (u >> 1) & 0x5555555555555555ull;
-        if constexpr (NLOG > 5) u ^= (u >> 2) & 0x3333333333333333ull;
-        if constexpr (NLOG > 6) u ^= (u >> 4) & 0x0F0F0F0F0F0F0F0Full;
-        if constexpr (NLOG > 7) u ^= (u >> 8) & 0x00FF00FF00FF00FFull;
-        if constexpr (NLOG > 8) u ^= (u >> 16) & 0x0000FFFF0000FFFFull;
-        if constexpr (NLOG > 9) u ^= (u >> 32) & 0x00000000FFFFFFFFull;
-        // stages 0 .. 3 pair lanes (l, l + 2^s) of the row: row_shl:n makes lane i read lane i + n
-        {
-            uint32_t lo = (uint32_t)u, hi = (uint32_t)(u >> 32);
-            uint32_t t;
-            t = dpp_mov_u32<0x101>(lo); lo ^= (sub & 1) ? 0u : t; t = dpp_mov_u32<0x101>(hi); hi ^= (sub & 1) ? 0u : t;
-            t = dpp_mov_u32<0x102>(lo); lo ^= (sub & 2) ? 0u : t; t = dpp_mov_u32<0x102>(hi); hi ^= (sub & 2) ? 0u : t;
-            t = dpp_mov_u32<0x104>(lo); lo ^= (sub & 4) ? 0u : t; t = dpp_mov_u32<0x104>(hi); hi ^= (sub & 4) ? 0u : t;
-            t = dpp_mov_u32<0x108>(lo); lo ^= (sub & 8) ? 0u : t; t = dpp_mov_u32<0x108>(hi); hi ^= (sub & 8) ? 0u : t;
-            stage[lane * 2] = lo;
-            stage[lane * 2 + 1] = hi;
-        }
-        wave_sync();
-        if (info_hat) {
-            uint32_t *dst = info_hat + fc * Kw;
-            const uint32_t *mine = stage + grp * 32;
-            // lane `sub` keeps output words sub and sub + 16; the frame's words then leave as one
-            // contiguous 64-byte store per 16 words instead of sixteen scattered 4-byte stores
-            uint32_t w_lo = 0, w_hi = 0;
-            pack_bits_group<16>(
-                K, sub, grp,
-                [&](int k) {
-                    uint32_t a = Asl[k];  // (lane << 6) | bit
-                    return ((mine[(a >> 6) * 2 + ((a >> 5) & 1u)] >> (a & 31u)) & 1u) != 0u;
-                },
-                [&](int wi, uint32_t v) {
-                    if ((wi & 15) == sub) {
-                        if (wi < 16) w_lo = v;
-                        else w_hi = v;
-                    }
-                });
-            if (active) {
-                if (sub < Kw) dst[sub] = w_lo;
-                if (sub + 16 < Kw) dst[sub + 16] = w_hi;
-            }
-            if (K == 0 && sub == 0 && active) dst[0] = 0u;
-        }
-        wave_sync();
+        sc_reg_epilogue<NLOG>(d.root, stage, Asl, info_hat, fc, active, lane, K, Kw);
     }
 }
 
@@ -296,6 +193,10 @@ template <typename T> static int launch_reg_n(polar_code *c, const void *llr, ui
 int launch_sc_reg(polar_code *c, const void *llr, int dtype, uint32_t *info_hat, int64_t B, int flags)
 {
     if (B == 0) return POLAR_OK;
+    if (c->static_fn && (flags & POLAR_SC_FAST) && dtype == POLAR_F32) {
+        const char *e = getenv("POLAR_SC_KERNEL");
+        if (!(e && e[0] == 'g')) return launch_sc_static(c, llr, info_hat, B);  // "generic": keep the generic kernel
+    }
     if (dtype != POLAR_F32) {
         polar_set_error("register SC kernel: fp32 only");
         return POLAR_EUNSUPPORTED;

@@ -1,0 +1,216 @@
+// Register-resident SC decoder state, and the decoder specialised at compile time for one rate profile.
+//
+// This header is device code only (it needs <hip/hip_runtime.h> and <stdint.h>, nothing from the host side), so
+// that the run-time compiler can build it: with POLAR_STATIC_NLOG and POLAR_STATIC_WORDS defined (log2 N and
+// the N/32 rate-profile words, bit i of word w = position 32 w + i carries information) it also defines the
+// kernel sc_static_kernel, in which every decision about the code tree -- which nodes are all-frozen or
+// all-information, the profile of every 16-leaf node, the plane a node's sums go to -- is a compile-time
+// constant.  The result is straight-line code: no loop, no branch, no scalar bookkeeping in the tree walk
+// (unrolled decoders in the sense of Giard et al.).  Arithmetic and results are those of sc_reg_kernel.
+#pragma once
+#include "reg_common.h"
+
+typedef uint64_t ps_t;
+
+template <typename T, int NLOG> struct RegDec {
+    static constexpr int S = 1 << (NLOG - 4);  // slice length per lane
+    T R[S];                                    // level l (4 <= l < NLOG): 2^(l-4) values at offset 2^(l-4)
+    ps_t ps0, ps1;                             // partial sums (plane 0 / 1), same offsets, one bit per value
+    ps_t root;
+
+    // f or g from level LEV to LEV-1 (5 <= LEV <= NLOG); the top level reads the channel from memory
+    template <int LEV, bool IS_G> __device__ __forceinline__ void step(const T *chan_lane)
+    {
+        constexpr int c = 1 << (LEV - 5);
+#pragma unroll
+        for (int j = 0; j < c; j++) {
+            T a, b;
+            if constexpr (LEV == NLOG) {
+                a = chan_lane[16 * j];
+                b = chan_lane[16 * (j + c)];
+            } else {
+                a = R[2 * c + j];
+                b = R[3 * c + j];
+            }
+            if constexpr (IS_G) R[c + j] = g_fast(a, b, (uint32_t)(ps0 >> (c + j)) & 1u);
+            else R[c + j] = f_fast(a, b);
+        }
+    }
+    template <int LEV> __device__ __forceinline__ void combine(int plane)
+    {
+        constexpr int c = 1 << (LEV - 5);
+        const ps_t m = (c >= 64) ? ~(ps_t)0 : (((ps_t)1 << c) - 1);
+        const ps_t xl = (ps0 >> c) & m, xr = (ps1 >> c) & m;
+        if constexpr (LEV == NLOG) {
+            root = (xl ^ xr) | (c >= 64 ? 0 : (xr << c));
+        } else {
+            const ps_t x = (xl ^ xr) | (xr << c);
+            const ps_t m2 = (((ps_t)1 << (2 * c)) - 1) << (2 * c);
+            if (plane) ps1 = (ps1 & ~m2) | (x << (2 * c));
+            else ps0 = (ps0 & ~m2) | (x << (2 * c));
+        }
+    }
+    template <int LEV> __device__ __forceinline__ void rate0(int plane)
+    {
+        constexpr int c = 1 << (LEV - 4);
+        const ps_t m2 = (((ps_t)1 << c) - 1) << c;
+        if (plane) ps1 &= ~m2;
+        else ps0 &= ~m2;
+    }
+    template <int LEV> __device__ __forceinline__ void rate1(int plane)
+    {
+        constexpr int c = 1 << (LEV - 4);
+        ps_t x = 0;
+#pragma unroll
+        for (int j = 0; j < c; j++) x |= (ps_t)(R[c + j] < (T)0 ? 1u : 0u) << j;
+        const ps_t m2 = (((ps_t)1 << c) - 1) << c;
+        if (plane) ps1 = (ps1 & ~m2) | (x << c);
+        else ps0 = (ps0 & ~m2) | (x << c);
+    }
+};
+
+
+// ---- compile-time rate profile --------------------------------------------------------------------------------
+template <int NW> struct StaticProfile {
+    uint32_t w[NW];
+    // information leaves of node idx at level lev (2^lev leaves)
+    constexpr int ninfo(int lev, int idx) const
+    {
+        int c = 0;
+        for (int i = 0; i < (1 << lev); i++) {
+            const int pos = (idx << lev) + i;
+            c += (int)((w[pos >> 5] >> (pos & 31)) & 1u);
+        }
+        return c;
+    }
+    constexpr uint32_t mask16(int idx) const { return (w[idx >> 1] >> (16 * (idx & 1))) & 0xFFFFu; }
+};
+
+// Node idx of level LEV (>= 5), not all-frozen and not all-information; PLANE = 0 left child, 1 right child.
+template <typename P, int LEV, int IDX, int PLANE, int NLOG, typename T>
+__device__ __forceinline__ void decode_static(RegDec<T, NLOG> &d, const T *chan_lane, const RowConst &rc)
+{
+    constexpr auto prof = P::value();  // StaticProfile<N/32>
+    constexpr int full = 1 << (LEV - 1);
+    constexpr int nl = prof.ninfo(LEV - 1, 2 * IDX), nr = prof.ninfo(LEV - 1, 2 * IDX + 1);
+    // left child (an all-frozen left child needs no LLRs: its sums are zero)
+    if constexpr (nl == 0) {
+        d.template rate0<LEV - 1>(0);
+    } else {
+        d.template step<LEV, false>(chan_lane);
+        if constexpr (nl == full) {
+            d.template rate1<LEV - 1>(0);
+        } else if constexpr (LEV - 1 == 4) {
+            const uint32_t x = sub_node_c<16, prof.mask16(2 * IDX)>(d.R[1], rc);
+            d.ps0 = (d.ps0 & ~(ps_t)2) | ((ps_t)x << 1);
+        } else {
+            decode_static<P, LEV - 1, 2 * IDX, 0, NLOG>(d, chan_lane, rc);
+        }
+    }
+    // right child
+    if constexpr (nr == 0) {
+        d.template rate0<LEV - 1>(1);
+    } else {
+        d.template step<LEV, true>(chan_lane);
+        if constexpr (nr == full) {
+            d.template rate1<LEV - 1>(1);
+        } else if constexpr (LEV - 1 == 4) {
+            const uint32_t x = sub_node_c<16, prof.mask16(2 * IDX + 1)>(d.R[1], rc);
+            d.ps1 = (d.ps1 & ~(ps_t)2) | ((ps_t)x << 1);
+        } else {
+            decode_static<P, LEV - 1, 2 * IDX + 1, 1, NLOG>(d, chan_lane, rc);
+        }
+    }
+    d.template combine<LEV>(PLANE);
+}
+
+// Output stage shared with sc_reg_kernel: u_hat = x_hat F^{(x)n} on the sliced layout, then the information
+// bits gathered through LDS (stage: 128 words per wavefront) and stored as whole words.
+template <int NLOG>
+__device__ __forceinline__ void sc_reg_epilogue(ps_t root, uint32_t *stage, const uint32_t *__restrict__ Asl, uint32_t *__restrict__ info_hat,
+                                                int64_t fc, bool active, int lane, int K, int Kw)
+{
+    const int grp = lane >> 4, sub = lane & 15;
+    ps_t u = root;
+    // stages 4 .. NLOG-1 pair (j, j + 2^(s-4)) inside a lane
+    if constexpr (NLOG > 4) u ^= (u >> 1) & 0x5555555555555555ull;
+    if constexpr (NLOG > 5) u ^= (u >> 2) & 0x3333333333333333ull;
+    if constexpr (NLOG > 6) u ^= (u >> 4) & 0x0F0F0F0F0F0F0F0Full;
+    if constexpr (NLOG > 7) u ^= (u >> 8) & 0x00FF00FF00FF00FFull;
+    if constexpr (NLOG > 8) u ^= (u >> 16) & 0x0000FFFF0000FFFFull;
+    if constexpr (NLOG > 9) u ^= (u >> 32) & 0x00000000FFFFFFFFull;
+    // stages 0 .. 3 pair lanes (l, l + 2^s) of the row: row_shl:n makes lane i read lane i + n
+    {
+        uint32_t lo = (uint32_t)u, hi = (uint32_t)(u >> 32);
+        uint32_t t;
+        t = dpp_mov_u32<0x101>(lo); lo ^= (sub & 1) ? 0u : t; t = dpp_mov_u32<0x101>(hi); hi ^= (sub & 1) ? 0u : t;
+        t = dpp_mov_u32<0x102>(lo); lo ^= (sub & 2) ? 0u : t; t = dpp_mov_u32<0x102>(hi); hi ^= (sub & 2) ? 0u : t;
+        t = dpp_mov_u32<0x104>(lo); lo ^= (sub & 4) ? 0u : t; t = dpp_mov_u32<0x104>(hi); hi ^= (sub & 4) ? 0u : t;
+        t = dpp_mov_u32<0x108>(lo); lo ^= (sub & 8) ? 0u : t; t = dpp_mov_u32<0x108>(hi); hi ^= (sub & 8) ? 0u : t;
+        stage[lane * 2] = lo;
+        stage[lane * 2 + 1] = hi;
+    }
+    wave_sync();
+    if (info_hat) {
+        uint32_t *dst = info_hat + fc * Kw;
+        const uint32_t *mine = stage + grp * 32;
+        // lane `sub` keeps output words sub and sub + 16; the frame's words then leave as one
+        // contiguous 64-byte store per 16 words instead of sixteen scattered 4-byte stores
+        uint32_t w_lo = 0, w_hi = 0;
+        pack_bits_group<16>(
+            K, sub, grp,
+            [&](int k) {
+                uint32_t a = Asl[k];  // (lane << 6) | bit
+                return ((mine[(a >> 6) * 2 + ((a >> 5) & 1u)] >> (a & 31u)) & 1u) != 0u;
+            },
+            [&](int wi, uint32_t v) {
+                if ((wi & 15) == sub) {
+                    if (wi < 16) w_lo = v;
+                    else w_hi = v;
+                }
+            });
+        if (active) {
+            if (sub < Kw) dst[sub] = w_lo;
+            if (sub + 16 < Kw) dst[sub + 16] = w_hi;
+        }
+        if (K == 0 && sub == 0 && active) dst[0] = 0u;
+    }
+    wave_sync();
+}
+
+#if defined(POLAR_STATIC_NLOG) && defined(POLAR_STATIC_WORDS)
+struct PolarStaticProfile {
+    static constexpr StaticProfile<((1 << POLAR_STATIC_NLOG) + 31) / 32> value()
+    {
+        return StaticProfile<((1 << POLAR_STATIC_NLOG) + 31) / 32>{{POLAR_STATIC_WORDS}};
+    }
+};
+
+extern "C" __global__ void __launch_bounds__(64, 4) sc_static_kernel(const float *__restrict__ llr, const uint32_t *__restrict__ Asl,
+                                                                    uint32_t *__restrict__ info_hat, long long B, int K, int Kw)
+{
+    __shared__ uint32_t stage[4 * 16 * 2];
+    constexpr int NLOG = POLAR_STATIC_NLOG;
+    constexpr int N = 1 << NLOG;
+    const int lane = threadIdx.x;
+    const int grp = lane >> 4;
+    const int sub = lane & 15;
+    RegDec<float, NLOG> d;
+    RowConst rc;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        rc.up[i] = (sub & (8 >> i)) != 0;
+        rc.lowmask[i] = rc.up[i] ? 0u : 0xFFFFFFFFu;
+    }
+    for (long long f0 = (long long)blockIdx.x * 4; f0 < B; f0 += (long long)gridDim.x * 4) {
+        const long long f = f0 + grp;
+        const bool active = f < B;
+        const long long fc = active ? f : B - 1;
+        const float *chan_lane = llr + fc * N + sub;
+        d.ps0 = d.ps1 = 0;
+        d.root = 0;
+        decode_static<PolarStaticProfile, NLOG, 0, 0, NLOG>(d, chan_lane, rc);
+        sc_reg_epilogue<NLOG>(d.root, stage, Asl, info_hat, fc, active, lane, K, Kw);
+    }
+}
+#endif

@@ -232,6 +232,7 @@ extern "C" int polar_code_destroy(polar_code *c)
     void *qs[] = {c->d_S0, c->d_crit_off, c->d_crit_idx, c->d_sqrt_mu};
     for (void *p : qs)
         if (p) (void)hipFree(p);
+    if (c->static_mod) (void)hipModuleUnload(c->static_mod);
     delete c;
     return POLAR_OK;
 }

@@ -99,6 +99,9 @@ struct polar_code {
     double *d_sqrt_mu = nullptr;
     int nS0 = 0, maxS = 0;
     bool have_mu = false, have_crit = false;
+    // decoder compiled at run time for this rate profile (polar_code_specialize), or null
+    hipModule_t static_mod = nullptr;
+    hipFunction_t static_fn = nullptr;
     polar_launch_info last{};
 };
 
@@ -128,6 +131,8 @@ int launch_pbf(polar_code *c, const void *llr, int dtype, const uint32_t *rows, 
                void *dec_llr, int32_t *runs, uint8_t *crc_ok, int32_t *last_seq, int64_t B);
 int launch_crc_filter(polar_code *c, const uint32_t *info_hat, uint32_t *rows, unsigned long long *nrows, int32_t *runs,
                       uint8_t *crc_ok, int32_t *last_seq, int64_t B);
+
+int launch_sc_static(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B);
 
 // timing bracket around the dominant kernel of a call
 struct LaunchTimer {

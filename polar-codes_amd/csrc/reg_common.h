@@ -1,8 +1,10 @@
 // Device helpers shared by the register-resident decoder kernels: DPP lane exchanges and the fp32
 // f / g forms that stay on the vector ALU.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 #include "decode_common.h"
 

@@ -71,6 +71,9 @@ def native_runner(pcode, decoder, L, dtype, crc=False, genie=False):
     import _native
 
     dec = {"scl": _native.DEC_SCL, "pbf": _native.DEC_PBF}.get(decoder, _native.DEC_SC)
+    if dec != _native.DEC_SCL and np.dtype(dtype) == np.float32 and 32 <= pcode.codewordLength <= 1024 \
+            and 0 < pcode.infoLen < pcode.codewordLength:
+        pcode.native.specialize()  # SC runs of a whole sweep repay the seconds the run-time compiler takes
     if crc:
         pcode._attach_crc()
     if decoder == "pbf":

@@ -89,3 +89,14 @@ def test_schedule_edge_profiles():
         uh = oracle.sc_decode(llr, mask)
         assert np.array_equal(run_schedule(plain, llr, 16)[0], uh)
         assert np.array_equal(run_schedule(fast, llr, 16)[0], uh)
+
+
+def test_run_time_compiler_builds_the_specialised_decoder():
+    """polar_static_compile_check needs no GPU: the HIP run-time compiler turns the unrolled decoder of a rate
+    profile into a gfx950 code object."""
+    size = _native.static_compile_check(pcf.degaBuild(256, 128, 2.0), "gfx950")
+    assert size > 4096
+    with pytest.raises(_native.PolarError):
+        _native.static_compile_check(np.ones(64, dtype=int))      # K = N: nothing to specialise
+    with pytest.raises(_native.PolarError):
+        _native.static_compile_check(pcf.degaBuild(2048, 1024, 2.0))

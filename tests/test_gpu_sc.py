@@ -206,3 +206,34 @@ def test_sc_every_compiled_16_leaf_profile(monkeypatch):
                 info, _, _ = code.sc_decode(llr, fast=fast)
                 assert code.last_launch()["kernel"].startswith("sc_reg_kernel")
                 assert np.array_equal(info, ref), fast
+
+
+@pytest.mark.parametrize("N,K", [(32, 16), (64, 20), (128, 64), (256, 200), (512, 100), (1024, 512)])
+def test_sc_specialised_kernel_equals_generic(monkeypatch, N, K):
+    """The decoder compiled at run time for one rate profile against the generic register kernel and the oracle."""
+    rs = np.random.RandomState(N + K)
+    for mask in (pcf.degaBuild(N, K, 2.0), np.r_[0, (rs.rand(N - 2) < 0.5).astype(int), 1]):
+        code = _native.Code(_native.default_ctx(), mask)
+        Kc = int(mask.sum())
+        x = oracle.polar_encode(rs.randint(0, 2, size=(203, Kc)), mask)
+        llr = code.channel_llr(x, n0_of(1.5, Kc / N), 9, 0, np.float32)
+        a, _, _ = code.sc_decode(llr, fast=True)
+        assert code.last_launch()["kernel"].startswith("sc_reg_kernel")
+        code.specialize()
+        b, _, _ = code.sc_decode(llr, fast=True)
+        assert code.last_launch()["kernel"].startswith("sc_static_kernel"), code.last_launch()
+        assert np.array_equal(a, b)
+        ref = np.stack([oracle.extract(oracle.sc_decode(llr[f], mask), mask) for f in range(0, 203, 7)])
+        assert np.array_equal(b[::7], ref)
+        monkeypatch.setenv("POLAR_SC_KERNEL", "generic")
+        c, _, _ = code.sc_decode(llr, fast=True)
+        assert code.last_launch()["kernel"].startswith("sc_reg_kernel")
+        monkeypatch.delenv("POLAR_SC_KERNEL")
+        # the fused Monte-Carlo loop picks the specialised decoder up as well
+        plain = _native.Code(_native.default_ctx(), mask)
+        n0 = n0_of(2.0, Kc / N)
+        assert code.mc_run(_native.DEC_SC, 1, np.float32, n0, 5, 0, 20000).tolist() == plain.mc_run(_native.DEC_SC, 1, np.float32, n0, 5, 0, 20000).tolist()
+
+
+def n0_of(snr_db, rate):
+    return 1.0 / (rate * 10 ** (snr_db / 10))
