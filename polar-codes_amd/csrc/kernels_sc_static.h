@@ -12,9 +12,12 @@
 
 typedef uint64_t ps_t;
 
-template <typename T, int NLOG> struct RegDec {
+template <typename T, int NLOG, int KEEP = 0> struct RegDec {
     static constexpr int S = 1 << (NLOG - 4);  // slice length per lane
     T R[S];                                    // level l (4 <= l < NLOG): 2^(l-4) values at offset 2^(l-4)
+    // the first KEEP channel pairs of the lane's slice stay in registers between the top-level f and g, the rest
+    // is read from memory a second time
+    T CA[KEEP > 0 ? KEEP : 1], CB[KEEP > 0 ? KEEP : 1];
     ps_t ps0, ps1;                             // partial sums (plane 0 / 1), same offsets, one bit per value
     ps_t root;
 
@@ -26,8 +29,17 @@ template <typename T, int NLOG> struct RegDec {
         for (int j = 0; j < c; j++) {
             T a, b;
             if constexpr (LEV == NLOG) {
-                a = chan_lane[16 * j];
-                b = chan_lane[16 * (j + c)];
+                if (IS_G && j < KEEP) {
+                    a = CA[j];
+                    b = CB[j];
+                } else {
+                    a = chan_lane[16 * j];
+                    b = chan_lane[16 * (j + c)];
+                    if (!IS_G && j < KEEP) {
+                        CA[j] = a;
+                        CB[j] = b;
+                    }
+                }
             } else {
                 a = R[2 * c + j];
                 b = R[3 * c + j];
@@ -87,8 +99,8 @@ template <int NW> struct StaticProfile {
 };
 
 // Node idx of level LEV (>= 5), not all-frozen and not all-information; PLANE = 0 left child, 1 right child.
-template <typename P, int LEV, int IDX, int PLANE, int NLOG, typename T>
-__device__ __forceinline__ void decode_static(RegDec<T, NLOG> &d, const T *chan_lane, const RowConst &rc)
+template <typename P, int LEV, int IDX, int PLANE, int NLOG, int KEEP, typename T>
+__device__ __forceinline__ void decode_static(RegDec<T, NLOG, KEEP> &d, const T *chan_lane, const RowConst &rc)
 {
     constexpr auto prof = P::value();  // StaticProfile<N/32>
     constexpr int full = 1 << (LEV - 1);
@@ -104,7 +116,7 @@ __device__ __forceinline__ void decode_static(RegDec<T, NLOG> &d, const T *chan_
             const uint32_t x = sub_node_c<16, prof.mask16(2 * IDX)>(d.R[1], rc);
             d.ps0 = (d.ps0 & ~(ps_t)2) | ((ps_t)x << 1);
         } else {
-            decode_static<P, LEV - 1, 2 * IDX, 0, NLOG>(d, chan_lane, rc);
+            decode_static<P, LEV - 1, 2 * IDX, 0, NLOG, KEEP>(d, chan_lane, rc);
         }
     }
     // right child
@@ -118,7 +130,7 @@ __device__ __forceinline__ void decode_static(RegDec<T, NLOG> &d, const T *chan_
             const uint32_t x = sub_node_c<16, prof.mask16(2 * IDX + 1)>(d.R[1], rc);
             d.ps1 = (d.ps1 & ~(ps_t)2) | ((ps_t)x << 1);
         } else {
-            decode_static<P, LEV - 1, 2 * IDX + 1, 1, NLOG>(d, chan_lane, rc);
+            decode_static<P, LEV - 1, 2 * IDX + 1, 1, NLOG, KEEP>(d, chan_lane, rc);
         }
     }
     d.template combine<LEV>(PLANE);
@@ -186,7 +198,13 @@ struct PolarStaticProfile {
     }
 };
 
-extern "C" __global__ void __launch_bounds__(64, 4) sc_static_kernel(const float *__restrict__ llr, const uint32_t *__restrict__ Asl,
+#ifndef POLAR_STATIC_KEEP
+#define POLAR_STATIC_KEEP 0
+#endif
+#ifndef POLAR_STATIC_WAVES
+#define POLAR_STATIC_WAVES 4
+#endif
+extern "C" __global__ void __launch_bounds__(64, POLAR_STATIC_WAVES) sc_static_kernel(const float *__restrict__ llr, const uint32_t *__restrict__ Asl,
                                                                     uint32_t *__restrict__ info_hat, long long B, int K, int Kw)
 {
     __shared__ uint32_t stage[4 * 16 * 2];
@@ -195,7 +213,7 @@ extern "C" __global__ void __launch_bounds__(64, 4) sc_static_kernel(const float
     const int lane = threadIdx.x;
     const int grp = lane >> 4;
     const int sub = lane & 15;
-    RegDec<float, NLOG> d;
+    RegDec<float, NLOG, POLAR_STATIC_KEEP> d;
     RowConst rc;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -209,7 +227,7 @@ extern "C" __global__ void __launch_bounds__(64, 4) sc_static_kernel(const float
         const float *chan_lane = llr + fc * N + sub;
         d.ps0 = d.ps1 = 0;
         d.root = 0;
-        decode_static<PolarStaticProfile, NLOG, 0, 0, NLOG>(d, chan_lane, rc);
+        decode_static<PolarStaticProfile, NLOG, 0, 0, NLOG, POLAR_STATIC_KEEP>(d, chan_lane, rc);
         sc_reg_epilogue<NLOG>(d.root, stage, Asl, info_hat, fc, active, lane, K, Kw);
     }
 }

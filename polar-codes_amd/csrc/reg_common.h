@@ -44,20 +44,32 @@ __device__ __forceinline__ uint32_t pin(uint32_t x)
 }
 __device__ __forceinline__ float minabs(float a, float b)
 {
+#if defined(__FINITE_MATH_ONLY__) && __FINITE_MATH_ONLY__
+    // no NaN to quiet: the compiler folds the absolute values into the minimum's source modifiers itself and,
+    // unlike around inline assembly, needs no hazard padding
+    return __builtin_fminf(__builtin_fabsf(a), __builtin_fabsf(b));
+#else
     float m;
     asm("v_min_f32 %0, |%1|, |%2|" : "=v"(m) : "v"(a), "v"(b));
     return m;
+#endif
 }
 // sign(a) sign(b) min(|a|,|b|) in three vector instructions
 __device__ __forceinline__ float f_fast(float a, float b)
 {
-    uint32_t s = __float_as_uint(a) ^ __float_as_uint(b);
+    const uint32_t s = __float_as_uint(a) ^ __float_as_uint(b);
     return __uint_as_float((s & 0x80000000u) | __float_as_uint(minabs(a, b)));
 }
 __device__ __forceinline__ double f_fast(double a, double b) { return f_minsum(a, b); }
 // b + (bit ? -a : a) with the bit as an integer 0/1
 __device__ __forceinline__ float g_fast(float a, float b, uint32_t bit) { return b + __uint_as_float(__float_as_uint(a) ^ (bit << 31)); }
 __device__ __forceinline__ double g_fast(double a, double b, uint32_t bit) { return g_apply(a, b, bit); }
+// v with its sign inverted when bit (0/1) is set
+__device__ __forceinline__ float flip_sign(float v, uint32_t bit) { return __uint_as_float(__float_as_uint(v) ^ (bit << 31)); }
+__device__ __forceinline__ double flip_sign(double v, uint32_t bit)
+{
+    return __hiloint2double(__double2hiint(v) ^ (int)(bit << 31), __double2loint(v));
+}
 
 // ---- 16-leaf nodes decoded in registers by one DPP row ---------------------------------------------
 // Lane constants of the replicated butterfly: for period P, lanes whose element index is in the upper half.
@@ -100,21 +112,24 @@ template <int P, bool SHORT, typename T> __device__ __forceinline__ uint32_t sub
                     const T o4 = partner<4>(v);
                     const T vl4 = f_fast(v, o4);
                     const T sl = vl4 + partner<2>(vl4);
-                    const uint32_t xl4 = pin(sl < (T)0 ? 1u : 0u);
-                    const T lo4 = rc.up[I] ? o4 : v, hi4 = rc.up[I] ? v : o4;
-                    const T vr4 = g_fast(lo4, hi4, xl4);
+                    const uint32_t y4 = pin(sl < (T)0 ? 1u : 0u) & rc.lowmask[I];
+                    const T t4 = flip_sign(v, y4);
+                    const T vr4 = t4 + partner<4>(t4);
                     const uint32_t xr4 = pin(vr4 < (T)0 ? 1u : 0u);
-                    return xr4 ^ (xl4 & rc.lowmask[I]);
+                    return xr4 ^ y4;
                 }
             }
         }
+        // g without selecting lo / hi: the lanes of the lower half hold lo and apply the sign themselves, then
+        // every lane adds its partner's value (hi + (+-lo) and (+-lo) + hi are the same sum)
         const T o = partner<P>(v);
-        const T lo = rc.up[I] ? o : v, hi = rc.up[I] ? v : o;
         const T vl = f_fast(v, o);
         const uint32_t xl = sub_node<P / 2, SHORT>(vl, mask & HALF, rc);
-        const T vr = g_fast(lo, hi, xl);
+        const uint32_t y = xl & rc.lowmask[I];
+        const T t = flip_sign(v, y);
+        const T vr = t + partner<P>(t);
         const uint32_t xr = sub_node<P / 2, SHORT>(vr, (mask >> (P / 2)) & HALF, rc);
-        return xr ^ (xl & rc.lowmask[I]);
+        return xr ^ y;
     }
 }
 
@@ -141,12 +156,13 @@ template <int P, uint32_t MASK, typename T> __device__ __forceinline__ uint32_t 
             const T vr = v + o;
             return sub_node_c<P / 2, MR>(vr, rc);
         } else {
-            const T lo = rc.up[I] ? o : v, hi = rc.up[I] ? v : o;
             const T vl = f_fast(v, o);
             const uint32_t xl = sub_node_c<P / 2, ML>(vl, rc);
-            const T vr = g_fast(lo, hi, xl);
+            const uint32_t y = xl & rc.lowmask[I];
+            const T t = flip_sign(v, y);
+            const T vr = t + partner<P>(t);
             const uint32_t xr = sub_node_c<P / 2, MR>(vr, rc);
-            return xr ^ (xl & rc.lowmask[I]);
+            return xr ^ y;
         }
     }
 }
@@ -177,11 +193,12 @@ __device__ __forceinline__ uint32_t sub_node_flip(T v, uint32_t mask, const RowC
         constexpr uint32_t HALF = (1u << (P / 2)) - 1u;
         constexpr int I = P == 16 ? 0 : P == 8 ? 1 : P == 4 ? 2 : 3;
         const T o = partner<P>(v);
-        const T lo = rc.up[I] ? o : v, hi = rc.up[I] ? v : o;
         const T vl = f_fast(v, o);
         const uint32_t xl = sub_node_flip<P / 2, OFF>(vl, mask & HALF, rc, pos, fl0, fl1, fl2, dl, writer);
-        const T vr = g_fast(lo, hi, xl);
+        const uint32_t y = xl & rc.lowmask[I];
+        const T t = flip_sign(v, y);
+        const T vr = t + partner<P>(t);
         const uint32_t xr = sub_node_flip<P / 2, OFF + P / 2>(vr, (mask >> (P / 2)) & HALF, rc, pos, fl0, fl1, fl2, dl, writer);
-        return xr ^ (xl & rc.lowmask[I]);
+        return xr ^ y;
     }
 }

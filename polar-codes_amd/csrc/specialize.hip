@@ -1,6 +1,7 @@
 // Run-time specialisation: builds kernels_sc_static.h for one rate profile with hiprtc and launches the result.
 #include <hip/hiprtc.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -14,7 +15,11 @@ static int compile_static(const uint8_t *mask, int N, const char *arch, std::vec
 {
     int n = 0;
     while ((1 << n) < N) n++;
-    std::string src = "#define POLAR_STATIC_NLOG " + std::to_string(n) + "\n#define POLAR_STATIC_WORDS ";
+    std::string src;
+    // experiment knobs: channel pairs kept in registers per lane, and the occupancy the compiler aims for
+    if (const char *e = getenv("POLAR_STATIC_KEEP")) src += "#define POLAR_STATIC_KEEP " + std::to_string(atoi(e)) + "\n";
+    if (const char *e = getenv("POLAR_STATIC_WAVES")) src += "#define POLAR_STATIC_WAVES " + std::to_string(atoi(e)) + "\n";
+    src += "#define POLAR_STATIC_NLOG " + std::to_string(n) + "\n#define POLAR_STATIC_WORDS ";
     for (int w = 0; w < (N + 31) / 32; w++) {
         uint32_t v = 0;
         for (int i = 0; i < 32 && 32 * w + i < N; i++) v |= (uint32_t)(mask[32 * w + i] ? 1 : 0) << i;
@@ -32,8 +37,9 @@ static int compile_static(const uint8_t *mask, int N, const char *arch, std::vec
         return POLAR_EUNSUPPORTED;
     }
     const std::string archopt = std::string("--offload-arch=") + arch;
-    const char *opts[] = {archopt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off"};
-    r = hiprtcCompileProgram(prog, 4, opts);
+    // -ffinite-math-only: the decoder never produces or tests NaN / infinity; it lets min(|a|,|b|) be one instruction
+    const char *opts[] = {archopt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-ffinite-math-only"};
+    r = hiprtcCompileProgram(prog, 5, opts);
     if (r != HIPRTC_SUCCESS) {
         size_t ls = 0;
         hiprtcGetProgramLogSize(prog, &ls);

@@ -11,7 +11,7 @@ import csv,glob,collections
 for d in sorted(glob.glob('$R/gpurun_out/pmc_*/vm/*_counter_collection.csv')):
     agg=collections.defaultdict(list)
     for r in csv.DictReader(open(d)):
-        if 'sc_reg_kernel' in r['Kernel_Name'] or 'sc_decode_kernel' in r['Kernel_Name']:
+        if any(k in r['Kernel_Name'] for k in ('sc_reg_kernel','sc_decode_kernel','sc_static_kernel')):
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
     for k,v in agg.items():
         print(k, 'n=%d'%len(v), 'avg=%.4g'%(sum(v)/len(v)), 'per_pass(1M)=%.1f'%(sum(v)/len(v)/1e6))
