@@ -48,6 +48,7 @@ template <int G, typename Pred, typename Store>
 __device__ __forceinline__ void pack_bits_group(int count, int sub, int grp, Pred pred, Store store)
 {
     uint32_t acc = 0;
+#pragma unroll 4  // lets the table and bit reads of neighbouring iterations overlap
     for (int k0 = 0; k0 < count; k0 += G) {
         int k = k0 + sub;
         bool p = (k < count) && pred(k);

@@ -81,6 +81,9 @@ __global__ void __launch_bounds__(64, 4) sc_reg_kernel(const T *__restrict__ llr
 {
     __shared__ uint32_t stage[4 * 16 * 2];  // per frame: 16 lanes x 64-bit slice of u_hat
     constexpr int N = 1 << NLOG;
+    __shared__ uint32_t asl_s[N];           // the gather table of the output stage
+    for (int k = threadIdx.x; k < K; k += 64) asl_s[k] = Asl[k];
+    wave_sync();
     const int lane = threadIdx.x;
     const int grp = lane >> 4;
     const int sub = lane & 15;
@@ -103,7 +106,7 @@ __global__ void __launch_bounds__(64, 4) sc_reg_kernel(const T *__restrict__ llr
         d.root = 0;
         decode_node<NLOG, NLOG, FAST>(d, nc, maskv, pidv, chan_lane, 0u, 0, rc);
 
-        sc_reg_epilogue<NLOG>(d.root, stage, Asl, info_hat, fc, active, lane, K, Kw);
+        sc_reg_epilogue<NLOG>(d.root, stage, asl_s, info_hat, fc, active, lane, K, Kw);
     }
 }
 
@@ -170,7 +173,7 @@ template <typename T, int NLOG, bool FAST> static int launch_reg_t(polar_code *c
     snprintf(c->last.kernel, sizeof(c->last.kernel), "sc_reg_kernel<%s,%d>%s", sizeof(T) == 4 ? "float" : "double", NLOG,
              FAST ? "/fast" : "");
     c->last.lanes_per_frame = 16;
-    c->last.lds_bytes_per_block = 512;
+    c->last.lds_bytes_per_block = 512 + 4 * c->N;
     c->last.block_threads = 64;
     c->last.grid_blocks = (int)grid;
     c->last.last_ms = ms;

@@ -137,9 +137,11 @@ __device__ __forceinline__ void decode_static(RegDec<T, NLOG, KEEP> &d, const T 
 }
 
 // Output stage shared with sc_reg_kernel: u_hat = x_hat F^{(x)n} on the sliced layout, then the information
-// bits gathered through LDS (stage: 128 words per wavefront) and stored as whole words.
+// bits gathered through LDS (stage: 128 words per wavefront) and stored as whole words.  Asl is the gather table
+// (one word per information bit); the kernels keep it in LDS: a global load per gathered bit would put a memory
+// round trip into every iteration of the packing loop.
 template <int NLOG>
-__device__ __forceinline__ void sc_reg_epilogue(ps_t root, uint32_t *stage, const uint32_t *__restrict__ Asl, uint32_t *__restrict__ info_hat,
+__device__ __forceinline__ void sc_reg_epilogue(ps_t root, uint32_t *stage, const uint32_t *Asl, uint32_t *__restrict__ info_hat,
                                                 int64_t fc, bool active, int lane, int K, int Kw)
 {
     const int grp = lane >> 4, sub = lane & 15;
@@ -210,6 +212,9 @@ extern "C" __global__ void __launch_bounds__(64, POLAR_STATIC_WAVES) sc_static_k
     __shared__ uint32_t stage[4 * 16 * 2];
     constexpr int NLOG = POLAR_STATIC_NLOG;
     constexpr int N = 1 << NLOG;
+    __shared__ uint32_t asl_s[N];
+    for (int k = threadIdx.x; k < K; k += 64) asl_s[k] = Asl[k];
+    wave_sync();
     const int lane = threadIdx.x;
     const int grp = lane >> 4;
     const int sub = lane & 15;
@@ -228,7 +233,7 @@ extern "C" __global__ void __launch_bounds__(64, POLAR_STATIC_WAVES) sc_static_k
         d.ps0 = d.ps1 = 0;
         d.root = 0;
         decode_static<PolarStaticProfile, NLOG, 0, 0, NLOG, POLAR_STATIC_KEEP>(d, chan_lane, rc);
-        sc_reg_epilogue<NLOG>(d.root, stage, Asl, info_hat, fc, active, lane, K, Kw);
+        sc_reg_epilogue<NLOG>(d.root, stage, asl_s, info_hat, fc, active, lane, K, Kw);
     }
 }
 #endif

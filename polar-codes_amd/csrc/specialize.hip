@@ -115,7 +115,7 @@ int launch_sc_static(polar_code *c, const void *llr, uint32_t *info_hat, int64_t
     float ms = tm.stop();
     snprintf(c->last.kernel, sizeof(c->last.kernel), "sc_static_kernel<%d>", c->n);
     c->last.lanes_per_frame = 16;
-    c->last.lds_bytes_per_block = 512;
+    c->last.lds_bytes_per_block = 512 + 4 * c->N;
     c->last.block_threads = 64;
     c->last.grid_blocks = (int)grid;
     c->last.last_ms = ms;
