@@ -68,7 +68,7 @@ struct PathState {
     float pm;
     uint32_t ownL;   // 3 bits per level l (index l - 3): position whose registers hold my level-l LLRs
     uint32_t ownP;   // same for the left-child partial sums of level l
-    float lo[3], hi[3];  // operands of the pending g of the enclosing 8-, 4- and 2-leaf nodes
+    float v[3];      // my element of the LLRs of the enclosing 8-, 4- and 2-leaf nodes, until their g has run
     uint32_t xb;     // bit I: partial-sum bit of the finished left child of the enclosing node I
 };
 
@@ -179,7 +179,8 @@ template <int NLOG> struct SclReg {
     }
 
     // ---- fork / prune: position lc.p becomes (parent position `par`, bit b) ------------------------------
-    __device__ __forceinline__ void take_over(float cpm, int par, uint32_t b, const LaneConst &lc)
+    // LIVE: bit I set = the g of the enclosing node I is still to come, so its saved LLR travels with the path
+    template <uint32_t LIVE> __device__ __forceinline__ void take_over(float cpm, int par, uint32_t b, const LaneConst &lc)
     {
         const int src = par * 8 + lc.q;
         st.pm = bperm_f(cpm, par * 8 + 4 * (int)b + (lc.q & 3));  // lanes q >= 4 hold the u=1 candidate metric
@@ -187,15 +188,13 @@ template <int NLOG> struct SclReg {
         st.ownP = bperm_u(st.ownP, src);
         st.xb = bperm_u(st.xb, src);
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
-            st.lo[i] = bperm_f(st.lo[i], src);
-            st.hi[i] = bperm_f(st.hi[i], src);
-        }
+        for (int i = 0; i < 3; i++)
+            if ((LIVE >> i) & 1u) st.v[i] = bperm_f(st.v[i], src);
     }
 
     // One leaf.  v is the decision LLR, replicated over the 8 lanes of each path.  Returns the decided bit of
     // the path that occupies this list position afterwards.
-    __device__ __forceinline__ uint32_t leaf(float v, uint32_t is_info, const LaneConst &lc, uint32_t *surv)
+    template <uint32_t LIVE> __device__ __forceinline__ uint32_t leaf(float v, uint32_t is_info, const LaneConst &lc, uint32_t *surv)
     {
         if (!is_info) {
             st.pm += branch_metric_fast(v, 0u);
@@ -231,26 +230,28 @@ template <int NLOG> struct SclReg {
             par = (int)(s >> 3);
             b = (s >> 2) & 1u;
         }
-        take_over(cpm, par, b, lc);
+        take_over<LIVE>(cpm, par, b, lc);
         return b;
     }
 
     // A node of P leaves inside the 8-leaf subtree; v replicated with period P over the path's lanes.
-    template <int P> __device__ __forceinline__ uint32_t sub(float v, uint32_t mask, const LaneConst &lc, uint32_t *surv)
+    template <int P, uint32_t LIVE = 0u>
+    __device__ __forceinline__ uint32_t sub(float v, uint32_t mask, const LaneConst &lc, uint32_t *surv)
     {
         if constexpr (P == 1) {
-            return leaf(v, mask & 1u, lc, surv);
+            return leaf<LIVE>(v, mask & 1u, lc, surv);
         } else {
             constexpr int I = P == 8 ? 0 : P == 4 ? 1 : 2;
             constexpr uint32_t HALF = (1u << (P / 2)) - 1u;
             const float o = partner8<P>(v);
-            st.lo[I] = lc.up[I] ? o : v;
-            st.hi[I] = lc.up[I] ? v : o;
+            st.v[I] = v;  // forks inside the left child move it along with the path
             const float vl = f_fast(v, o);
-            const uint32_t xl = sub<P / 2>(vl, mask & HALF, lc, surv);
+            const uint32_t xl = sub<P / 2, LIVE | (1u << I)>(vl, mask & HALF, lc, surv);
             st.xb = (st.xb & ~(1u << I)) | (xl << I);
-            const float vr = g_fast(st.lo[I], st.hi[I], xl);
-            const uint32_t xr = sub<P / 2>(vr, (mask >> (P / 2)) & HALF, lc, surv);
+            // g: the lanes of the lower half hold lo and apply the sign, then every lane adds its partner's value
+            const float t = flip_sign(st.v[I], xl & lc.lowmask[I]);
+            const float vr = t + partner8<P>(t);
+            const uint32_t xr = sub<P / 2, LIVE>(vr, (mask >> (P / 2)) & HALF, lc, surv);
             const uint32_t xl_now = (st.xb >> I) & 1u;  // the left result of whoever sits here now
             return xr ^ (xl_now & lc.lowmask[I]);
         }
@@ -292,6 +293,13 @@ __global__ void __launch_bounds__(64, 2) scl_reg_kernel(const float *__restrict_
     __shared__ uint32_t surv[8];
     __shared__ uint32_t stage[64 * 4];  // 8 paths x 8 lanes x 128-bit slice of u_hat
     constexpr int N = 1 << NLOG;
+    __shared__ uint32_t asl_s[N];       // the gather table of the output stage (and the CRC remainders) in LDS
+    __shared__ uint32_t crc_s[N];
+    for (int k = threadIdx.x; k < K; k += 64) {
+        asl_s[k] = Asl8[k];
+        if (crcS) crc_s[k] = crcS[k];
+    }
+    wave_sync();
     LaneConst lc;
     lc.lane = threadIdx.x;
     lc.p = lc.lane >> 3;
@@ -312,7 +320,7 @@ __global__ void __launch_bounds__(64, 2) scl_reg_kernel(const float *__restrict_
         d.st.ownL = d.st.ownP = 0u;
         d.st.xb = 0u;
 #pragma unroll
-        for (int i = 0; i < 3; i++) d.st.lo[i] = d.st.hi[i] = 0.0f;
+        for (int i = 0; i < 3; i++) d.st.v[i] = 0.0f;
         d.Lcur = 1;
         scl_node<NLOG, NLOG>(d, maskv, chan_lane, 0u, 0, lc, surv);
 
@@ -354,9 +362,9 @@ __global__ void __launch_bounds__(64, 2) scl_reg_kernel(const float *__restrict_
             pack_bits_group<8>(
                 K, lc.q, lc.p,
                 [&](int k) {
-                    const uint32_t a = Asl8[k];  // (lane-in-path << 7) | bit
+                    const uint32_t a = asl_s[k];  // (lane-in-path << 7) | bit
                     const bool bit = ((mine[(a >> 7) * 4 + ((a >> 5) & 3u)] >> (a & 31u)) & 1u) != 0u;
-                    if (crcS && bit) syn ^= crcS[k];
+                    if (crcS && bit) syn ^= crc_s[k];
                     return bit;
                 },
                 [&](int wi, uint32_t v) {
