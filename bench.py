@@ -120,7 +120,11 @@ def main():
     ctx = _native.default_ctx(local)
     code = _native.Code(ctx, mask)
     t0 = time.perf_counter()
-    code.specialize()  # per-code set-up: the SC decoder unrolled for this rate profile, built by the run-time compiler
+    specialize_error = None
+    try:
+        code.specialize()  # per-code set-up: the SC decoder unrolled for this rate profile, built by the run-time compiler
+    except _native.PolarError as e:  # the generic register kernel decodes the same bits, only slower
+        specialize_error = str(e)
     specialize_s = time.perf_counter() - t0
     ch = Channel("BPSK", a.snr, "SNRb", K / N)
     B = a.frames
@@ -227,6 +231,7 @@ def main():
             "counters": cnt,
             "input_gen_s": gen_s,
         "specialize_s": specialize_s,
+        "specialize_error": specialize_error,
             "scl8": scl,
             "roofline": {
                 "bound": "hbm",

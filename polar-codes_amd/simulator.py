@@ -73,7 +73,10 @@ def native_runner(pcode, decoder, L, dtype, crc=False, genie=False):
     dec = {"scl": _native.DEC_SCL, "pbf": _native.DEC_PBF}.get(decoder, _native.DEC_SC)
     if dec != _native.DEC_SCL and np.dtype(dtype) == np.float32 and 32 <= pcode.codewordLength <= 1024 \
             and 0 < pcode.infoLen < pcode.codewordLength:
-        pcode.native.specialize()  # SC runs of a whole sweep repay the seconds the run-time compiler takes
+        try:
+            pcode.native.specialize()  # SC runs of a whole sweep repay the time the run-time compiler takes
+        except _native.PolarError:
+            pass  # without the run-time compiler the generic GPU kernel decodes the same bits
     if crc:
         pcode._attach_crc()
     if decoder == "pbf":

@@ -162,6 +162,10 @@ def test_gpu_pbf_equals_oracle_on_random_frames(N, K, poly, T, nfr, dtype):
     assert got.tolist() == [nfr, fe, be]
     plain = code.mc_run(_native.DEC_SC, 1, npdt, n0, 77, 10, nfr, fast=True)
     assert got[1] <= plain[1]
+    if not dtype and N >= 32:
+        code.specialize()  # the first SC run of every frame then comes from the decoder compiled for this code
+        assert code.mc_run(_native.DEC_PBF, T, npdt, n0, 77, 10, nfr, crc=True).tolist() == got.tolist()
+        assert code.mc_run(_native.DEC_SC, 1, npdt, n0, 77, 10, nfr, fast=True).tolist() == plain.tolist()
 
 
 @pytest.mark.gpu

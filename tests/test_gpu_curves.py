@@ -70,3 +70,21 @@ def test_fp32_curves_inside_reference_confidence_intervals():
     for r in report:
         print("%-14s %.1f dB  FER gpu %.4e ref %.4e | BER gpu %.4e ref %.4e | in95 %s %s" % r)
     assert beyond95 <= 2, report
+
+
+def test_simulate_sweep_on_the_gpu_matches_mc_run():
+    """simulate() end to end on the GPU (single rank): fixed frame count, specialised decoder, same counters as
+    direct polar_mc_run calls with the same seeds."""
+    import simulator
+    from polarCode import PolarCode
+
+    pc = PolarCode(256, 128, "dega", 2.0)
+    pc.decoderType, pc.snrType, pc.modu = "sc", "SNRb", "BPSK"
+    res = simulator.simulate(pc, [1.0, 2.0], frames=50000, seed=11, verbose=False, batch=1 << 14)
+    assert pc.native.last_launch()["kernel"].startswith("sc_static_kernel")
+    ref = _native.Code(_native.default_ctx(), pc.polarMask)
+    for i, snr in enumerate([1.0, 2.0]):
+        n0 = Channel("BPSK", snr, "SNRb", 0.5).noisePower
+        c = ref.mc_run(_native.DEC_SC, 1, np.float32, n0, 11 + i, 0, 50000)
+        assert [res.frames[i], res.frameErrors[i], res.bitErrors[i]] == c.tolist()
+    assert res.fer[0] > res.fer[1] > 0
