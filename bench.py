@@ -367,7 +367,7 @@ def main():
             extras["ca_scl8_1024_512_crc24"] = {"error": str(e)}
         ctx.enable_timing(False)
         # fused Monte-Carlo pipeline (generate + decode + count), nothing resident beforehand
-        code.mc_run(_native.DEC_SC, 1, np.float32, ch.noisePower, seed, 0, 1 << 20)  # sizes the library's buffers
+        code.mc_run(_native.DEC_SC, 1, np.float32, ch.noisePower, seed, 0, (1 << 20) + 4096)  # sizes both buffers of the pipeline
         nmc = 1 << 24
         t0 = time.perf_counter()
         mc = code.mc_run(_native.DEC_SC, 1, np.float32, ch.noisePower, seed, 0, nmc)

@@ -65,6 +65,11 @@ extern "C" int polar_ctx_create(int device, polar_ctx **out)
     c->stream = c->own_stream;
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
+    HIP_TRY(hipStreamCreateWithFlags(&c->gen_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+        HIP_TRY(hipEventCreateWithFlags(&c->gen_done[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->dec_done[i], hipEventDisableTiming));
+    }
     *out = c;
     return POLAR_OK;
 }
@@ -75,10 +80,17 @@ extern "C" int polar_ctx_destroy(polar_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->in_bytes, &c->out_bytes, &c->in_words, &c->out_words, &c->llr_buf,   &c->aux_buf,  &c->aux2_buf,
-                      &c->pm_buf,   &c->counters,  &c->mc_info,  &c->mc_hat,    &c->flip_rows, &c->flip_ctr, &c->flip_small};
+                      &c->pm_buf,   &c->counters,  &c->mc_info,  &c->mc_hat,    &c->flip_rows, &c->flip_ctr, &c->flip_small,
+                      &c->mc_llr2,  &c->mc_info2};
     for (DevBuf *b : bufs) b->release();
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
+    (void)hipStreamSynchronize(c->gen_stream);
+    (void)hipStreamDestroy(c->gen_stream);
+    for (int i = 0; i < 2; i++) {
+        (void)hipEventDestroy(c->gen_done[i]);
+        (void)hipEventDestroy(c->dec_done[i]);
+    }
     (void)hipStreamDestroy(c->own_stream);
     delete c;
     return POLAR_OK;
@@ -836,29 +848,46 @@ extern "C" int polar_mc_run(polar_code *c, int decoder, int L, int dtype, int fl
     HIP_TRY(hipSetDevice(ctx->device));
     if (nframes == 0) return POLAR_OK;
     const size_t es = llr_size(dtype);
-    // chunk so that the LLR buffer stays around 1 GiB
-    int64_t chunk = std::max<int64_t>(1024, ((int64_t)1 << 30) / ((int64_t)c->N * (int64_t)es));
+    // chunks of about 4 GiB of LLRs (10^6 frames at N = 1024: long enough that the kernels' tails do not count), two buffers: chunk i+1 is generated on its own stream while chunk i is
+    // decoded and counted (the decoders leave registers and issue slots free that the generator can use)
+    int64_t chunk = std::max<int64_t>(1024, ((int64_t)1 << 32) / ((int64_t)c->N * (int64_t)es));
     chunk = std::min(chunk, nframes);
+    const bool two = nframes > chunk;
     int rc;
     if ((rc = ctx->llr_buf.reserve(chunk * c->N * es)) || (rc = ctx->mc_info.reserve(chunk * c->Kw * 4)) ||
         (rc = ctx->mc_hat.reserve(chunk * c->Kw * 4)) || (rc = ctx->counters.reserve(3 * sizeof(uint64_t))))
         return rc;
+    if (two && ((rc = ctx->mc_llr2.reserve(chunk * c->N * es)) || (rc = ctx->mc_info2.reserve(chunk * c->Kw * 4)))) return rc;
+    void *llr_b[2] = {ctx->llr_buf.p, two ? ctx->mc_llr2.p : ctx->llr_buf.p};
+    uint32_t *info_b[2] = {ctx->mc_info.as<uint32_t>(), two ? ctx->mc_info2.as<uint32_t>() : ctx->mc_info.as<uint32_t>()};
     uint64_t *dcnt = ctx->counters.as<uint64_t>();
-    HIP_TRY(hipMemsetAsync(dcnt, 0, 3 * sizeof(uint64_t), ctx->stream));
-    for (int64_t f0 = 0; f0 < nframes; f0 += chunk) {
-        int64_t nb = std::min(chunk, nframes - f0);
-        if ((rc = launch_gen_frames(c, ctx->mc_info.as<uint32_t>(), ctx->llr_buf.p, dtype, N0, seed, frame0 + f0, nb, crc))) return rc;
-        if (decoder == POLAR_DEC_SC)
-            rc = launch_sc_decode(c, ctx->llr_buf.p, dtype, ctx->mc_hat.as<uint32_t>(), nullptr, nullptr, nb, flags);
-        else if (decoder == POLAR_DEC_PBF)
-            rc = pbf_device(c, ctx->llr_buf.p, dtype, L, ctx->mc_hat.as<uint32_t>(), nullptr, nullptr, nullptr, nb);
-        else
-            rc = launch_scl_decode(c, ctx->llr_buf.p, dtype, L, ctx->mc_hat.as<uint32_t>(), nullptr, nullptr, nb, crc,
-                                   (flags & POLAR_GENIE) ? ctx->mc_info.as<uint32_t>() : nullptr);
+    hipStream_t main_stream = ctx->stream;
+    HIP_TRY(hipMemsetAsync(dcnt, 0, 3 * sizeof(uint64_t), main_stream));
+    // the generator must not overtake work the caller queued earlier on the context's stream
+    HIP_TRY(hipEventRecord(ctx->dec_done[1], main_stream));
+    HIP_TRY(hipStreamWaitEvent(ctx->gen_stream, ctx->dec_done[1], 0));
+    int64_t idx = 0;
+    for (int64_t f0 = 0; f0 < nframes; f0 += chunk, idx++) {
+        const int64_t nb = std::min(chunk, nframes - f0);
+        const int b = (int)(idx & 1);
+        // generate into buffer b once the decode that last read it (chunk idx-2) is done
+        if (idx >= 2) HIP_TRY(hipStreamWaitEvent(ctx->gen_stream, ctx->dec_done[b], 0));
+        ctx->stream = ctx->gen_stream;
+        rc = launch_gen_frames(c, info_b[b], llr_b[b], dtype, N0, seed, frame0 + f0, nb, crc);
+        ctx->stream = main_stream;
         if (rc) return rc;
-        if ((rc = launch_count_errors(c, ctx->mc_info.as<uint32_t>(), ctx->mc_hat.as<uint32_t>(), nb, dcnt,
-                                      crc ? c->K - c->crc_w : c->K)))
-            return rc;
+        HIP_TRY(hipEventRecord(ctx->gen_done[b], ctx->gen_stream));
+        HIP_TRY(hipStreamWaitEvent(main_stream, ctx->gen_done[b], 0));
+        if (decoder == POLAR_DEC_SC)
+            rc = launch_sc_decode(c, llr_b[b], dtype, ctx->mc_hat.as<uint32_t>(), nullptr, nullptr, nb, flags);
+        else if (decoder == POLAR_DEC_PBF)
+            rc = pbf_device(c, llr_b[b], dtype, L, ctx->mc_hat.as<uint32_t>(), nullptr, nullptr, nullptr, nb);
+        else
+            rc = launch_scl_decode(c, llr_b[b], dtype, L, ctx->mc_hat.as<uint32_t>(), nullptr, nullptr, nb, crc,
+                                   (flags & POLAR_GENIE) ? info_b[b] : nullptr);
+        if (rc) return rc;
+        if ((rc = launch_count_errors(c, info_b[b], ctx->mc_hat.as<uint32_t>(), nb, dcnt, crc ? c->K - c->crc_w : c->K))) return rc;
+        HIP_TRY(hipEventRecord(ctx->dec_done[b], main_stream));
     }
     uint64_t h[3];
     HIP_TRY(hipMemcpyAsync(h, dcnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));

@@ -70,8 +70,12 @@ struct polar_ctx {
     int num_cus = 0;
     int timing = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // Monte-Carlo pipeline: frames of chunk i+1 are generated on gen_stream while chunk i is decoded
+    hipStream_t gen_stream = nullptr;
+    hipEvent_t gen_done[2] = {nullptr, nullptr}, dec_done[2] = {nullptr, nullptr};
     // staging / scratch
     DevBuf in_bytes, out_bytes, in_words, out_words, llr_buf, aux_buf, aux2_buf, pm_buf, counters, mc_info, mc_hat;
+    DevBuf mc_llr2, mc_info2;  // second buffers of the Monte-Carlo pipeline
     DevBuf flip_rows, flip_ctr, flip_small;  // failing-frame list, {work counter, row count}, per-frame side outputs
 };
 
