@@ -151,8 +151,9 @@ def main():
     def step():
         counters.zero_()
         torch.cuda.synchronize()
-        code.sc_decode_dev(llr.data_ptr(), np.float32, hat.data_ptr(), B, fast=True)
-        code.count_errors_dev(info.data_ptr(), hat.data_ptr(), B, counters.data_ptr())
+        # decode, store the extracted information words and count the errors against the transmitted ones, one pass
+        code.sc_decode_count_dev(llr.data_ptr(), np.float32, info.data_ptr(), B, counters.data_ptr(), fast=True,
+                                 info_hat_ptr=hat.data_ptr())
         ctx.sync()
         if world > 1:
             all_reduce(counters)

@@ -180,6 +180,12 @@ int polar_pbf_decode_packed(polar_code *code, const void *llr, int dtype, int ma
 int polar_count_errors(polar_code *code, const uint32_t *info_packed, const uint32_t *info_hat_packed, int64_t B,
                        int flags, uint64_t *counters_dev);
 
+/* ---- decode and count in one pass: polar_sc_decode_packed followed by polar_count_errors, device buffers
+ *      only; where the register-resident kernels apply (fp32, N <= 1024) the comparison happens in the
+ *      decoder's output stage and info_hat may be NULL (the decoded words are then not stored at all). */
+int polar_sc_decode_count(polar_code *code, const void *llr, int dtype, const uint32_t *info_packed, uint32_t *info_hat,
+                          int64_t B, int flags, uint64_t *counters_dev);
+
 /* ---- fused Monte-Carlo run: the frame loop of cn/simulator.py:136-156,216-226 for global frame indices
  *      [frame0, frame0 + nframes).  Nothing but the three counters leaves the GPU.
  *      counters (host uint64[3]) are ADDED to. Frame f always sees the same inputs whatever the chunking

@@ -67,6 +67,7 @@ SIGNATURES = {
     "polar_sc_decode_flip": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _i]),
     "polar_pbf_decode": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _i]),
     "polar_pbf_decode_packed": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _i]),
+    "polar_sc_decode_count": (_i, [_vp, _vp, _i, _vp, _vp, _i64, _i, _vp]),
     "polar_count_errors": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "polar_mc_run": (_i, [_vp, _i, _i, _i, _i, _d, _u64, _u64, _i64, _vp]),
     "polar_last_launch": (_i, [_vp, C.POINTER(LaunchInfo)]),
@@ -309,6 +310,11 @@ class Code:
     def sc_decode_dev(self, llr_ptr, dtype, info_hat_ptr, B, fast=True, u_hat_ptr=None, dec_llr_ptr=None):
         _check(lib().polar_sc_decode_packed(self._h, llr_ptr, _dt(dtype), info_hat_ptr, u_hat_ptr, dec_llr_ptr, B,
                                             SC_FAST if fast else 0, DEVICE))
+
+    def sc_decode_count_dev(self, llr_ptr, dtype, info_ptr, B, counters_ptr, fast=True, info_hat_ptr=None):
+        """SC decode and error count in one pass (device buffers); the decoded words are stored only if asked for."""
+        _check(lib().polar_sc_decode_count(self._h, llr_ptr, _dt(dtype), info_ptr, info_hat_ptr, B, SC_FAST if fast else 0,
+                                           counters_ptr))
 
     def scl_decode_dev(self, llr_ptr, dtype, L, info_hat_ptr, B, pm_ptr=None, u_hat_ptr=None, crc=False):
         _check(lib().polar_scl_decode_packed(self._h, llr_ptr, _dt(dtype), L, info_hat_ptr, pm_ptr, u_hat_ptr, B,

@@ -77,7 +77,8 @@ __device__ __forceinline__ void decode_node(RegDec<T, NLOG> &d, const NodeClasse
 template <typename T, int NLOG, bool FAST>
 __global__ void __launch_bounds__(64, 4) sc_reg_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, NodeClasses nc,
                                                     const uint32_t *__restrict__ pid16, const uint32_t *__restrict__ Asl, uint32_t *__restrict__ info_hat, int64_t B,
-                                                    int K, int Kw)
+                                                    int K, int Kw, const uint32_t *__restrict__ truth, int nbits,
+                                                    unsigned long long *__restrict__ counters)
 {
     __shared__ uint32_t stage[4 * 16 * 2];  // per frame: 16 lanes x 64-bit slice of u_hat
     constexpr int N = 1 << NLOG;
@@ -88,6 +89,7 @@ __global__ void __launch_bounds__(64, 4) sc_reg_kernel(const T *__restrict__ llr
     const int grp = lane >> 4;
     const int sub = lane & 15;
     RegDec<T, NLOG> d;
+    ErrAcc acc;
     RowConst rc;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -106,8 +108,9 @@ __global__ void __launch_bounds__(64, 4) sc_reg_kernel(const T *__restrict__ llr
         d.root = 0;
         decode_node<NLOG, NLOG, FAST>(d, nc, maskv, pidv, chan_lane, 0u, 0, rc);
 
-        sc_reg_epilogue<NLOG>(d.root, stage, asl_s, info_hat, fc, active, lane, K, Kw);
+        sc_reg_epilogue<NLOG>(d.root, stage, asl_s, info_hat, fc, active, lane, K, Kw, truth, nbits, &acc);
     }
+    if (truth) err_acc_flush(acc, counters);
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -167,7 +170,8 @@ template <typename T, int NLOG, bool FAST> static int launch_reg_t(polar_code *c
     int64_t grid = std::min<int64_t>(need, (int64_t)ctx->num_cus * occ * 8);
     LaunchTimer tm(ctx);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), pad, ctx->stream, (const T *)llr, (const uint32_t *)c->d_maskw, nc,
-                       (const uint32_t *)c->d_pid16, (const uint32_t *)c->d_Asl, info_hat, B, c->K, c->Kw);
+                       (const uint32_t *)c->d_pid16, (const uint32_t *)c->d_Asl, info_hat, B, c->K, c->Kw, c->count_truth, c->count_nbits,
+                       (unsigned long long *)c->count_dev);
     HIP_TRY(hipGetLastError());
     float ms = tm.stop();
     snprintf(c->last.kernel, sizeof(c->last.kernel), "sc_reg_kernel<%s,%d>%s", sizeof(T) == 4 ? "float" : "double", NLOG,

@@ -140,9 +140,26 @@ __device__ __forceinline__ void decode_static(RegDec<T, NLOG, KEEP> &d, const T 
 // bits gathered through LDS (stage: 128 words per wavefront) and stored as whole words.  Asl is the gather table
 // (one word per information bit); the kernels keep it in LDS: a global load per gathered bit would put a memory
 // round trip into every iteration of the packing loop.
+// Error counting fused into the output stage: per-lane running sums of bit errors, frame errors and frames
+// (only the first lane of each frame's row counts), added to the global counters once per wavefront.
+struct ErrAcc {
+    uint32_t be = 0, fe = 0, fr = 0;
+};
+__device__ __forceinline__ void err_acc_flush(const ErrAcc &a, unsigned long long *counters)
+{
+    if (a.fr) {
+        atomicAdd(&counters[0], (unsigned long long)a.fr);
+        if (a.fe) atomicAdd(&counters[1], (unsigned long long)a.fe);
+        if (a.be) atomicAdd(&counters[2], (unsigned long long)a.be);
+    }
+}
+
+// truth (packed [B x Kw], or NULL): the transmitted information words; their first nbits bits are compared with the
+// decoded ones and the result goes into acc.  info_hat may then be NULL (nothing is stored).
 template <int NLOG>
 __device__ __forceinline__ void sc_reg_epilogue(ps_t root, uint32_t *stage, const uint32_t *Asl, uint32_t *__restrict__ info_hat,
-                                                int64_t fc, bool active, int lane, int K, int Kw)
+                                                int64_t fc, bool active, int lane, int K, int Kw,
+                                                const uint32_t *__restrict__ truth = nullptr, int nbits = 0, ErrAcc *acc = nullptr)
 {
     const int grp = lane >> 4, sub = lane & 15;
     ps_t u = root;
@@ -165,8 +182,7 @@ __device__ __forceinline__ void sc_reg_epilogue(ps_t root, uint32_t *stage, cons
         stage[lane * 2 + 1] = hi;
     }
     wave_sync();
-    if (info_hat) {
-        uint32_t *dst = info_hat + fc * Kw;
+    if (info_hat || truth) {
         const uint32_t *mine = stage + grp * 32;
         // lane `sub` keeps output words sub and sub + 16; the frame's words then leave as one
         // contiguous 64-byte store per 16 words instead of sixteen scattered 4-byte stores
@@ -183,11 +199,36 @@ __device__ __forceinline__ void sc_reg_epilogue(ps_t root, uint32_t *stage, cons
                     else w_hi = v;
                 }
             });
-        if (active) {
+        if (info_hat && active) {
+            uint32_t *dst = info_hat + fc * Kw;
             if (sub < Kw) dst[sub] = w_lo;
             if (sub + 16 < Kw) dst[sub + 16] = w_hi;
+            if (K == 0 && sub == 0) dst[0] = 0u;
         }
-        if (K == 0 && sub == 0 && active) dst[0] = 0u;
+        if (truth) {
+            const uint32_t *tw = truth + fc * Kw;
+            uint32_t e = 0;
+            if (sub < Kw) {
+                const int valid = nbits - 32 * sub;
+                const uint32_t m = valid >= 32 ? 0xFFFFFFFFu : (valid <= 0 ? 0u : ((1u << valid) - 1u));
+                e += __popc((w_lo ^ tw[sub]) & m);
+            }
+            if (sub + 16 < Kw) {
+                const int valid = nbits - 32 * (sub + 16);
+                const uint32_t m = valid >= 32 ? 0xFFFFFFFFu : (valid <= 0 ? 0u : ((1u << valid) - 1u));
+                e += __popc((w_hi ^ tw[sub + 16]) & m);
+            }
+            // sum over the 16 lanes of the frame's row
+            e += dpp_mov_u32<0x128>(e);
+            e += dpp_mov_u32<0x124>(e);
+            e += dpp_mov_u32<0x122>(e);
+            e += dpp_mov_u32<0x121>(e);
+            if (active && sub == 0) {
+                acc->be += e;
+                acc->fe += e ? 1u : 0u;
+                acc->fr += 1u;
+            }
+        }
     }
     wave_sync();
 }
@@ -207,7 +248,9 @@ struct PolarStaticProfile {
 #define POLAR_STATIC_WAVES 4
 #endif
 extern "C" __global__ void __launch_bounds__(64, POLAR_STATIC_WAVES) sc_static_kernel(const float *__restrict__ llr, const uint32_t *__restrict__ Asl,
-                                                                    uint32_t *__restrict__ info_hat, long long B, int K, int Kw)
+                                                                    uint32_t *__restrict__ info_hat, long long B, int K, int Kw,
+                                                                    const uint32_t *__restrict__ truth, int nbits,
+                                                                    unsigned long long *__restrict__ counters)
 {
     __shared__ uint32_t stage[4 * 16 * 2];
     constexpr int NLOG = POLAR_STATIC_NLOG;
@@ -219,6 +262,7 @@ extern "C" __global__ void __launch_bounds__(64, POLAR_STATIC_WAVES) sc_static_k
     const int grp = lane >> 4;
     const int sub = lane & 15;
     RegDec<float, NLOG, POLAR_STATIC_KEEP> d;
+    ErrAcc acc;
     RowConst rc;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -233,7 +277,8 @@ extern "C" __global__ void __launch_bounds__(64, POLAR_STATIC_WAVES) sc_static_k
         d.ps0 = d.ps1 = 0;
         d.root = 0;
         decode_static<PolarStaticProfile, NLOG, 0, 0, NLOG, POLAR_STATIC_KEEP>(d, chan_lane, rc);
-        sc_reg_epilogue<NLOG>(d.root, stage, asl_s, info_hat, fc, active, lane, K, Kw);
+        sc_reg_epilogue<NLOG>(d.root, stage, asl_s, info_hat, fc, active, lane, K, Kw, truth, nbits, &acc);
     }
+    if (truth) err_acc_flush(acc, counters);
 }
 #endif

@@ -823,6 +823,39 @@ extern "C" int polar_count_errors(polar_code *c, const uint32_t *info, const uin
     return launch_count_errors(c, info, hat, B, counters, (flags & POLAR_CRC) ? c->K - c->crc_w : c->K);
 }
 
+// SC decode + error count; nbits = leading bits of each information word that are compared
+static int sc_decode_count(polar_code *c, const void *llr, int dtype, const uint32_t *info, uint32_t *info_hat, int64_t B, int flags,
+                           uint64_t *counters, int nbits)
+{
+    if (B == 0) return POLAR_OK;
+    int rc;
+    if (sc_reg_supported(c, dtype, nullptr, nullptr)) {
+        c->count_truth = info;
+        c->count_nbits = nbits;
+        c->count_dev = counters;
+        rc = launch_sc_decode(c, llr, dtype, info_hat, nullptr, nullptr, B, flags);
+        c->count_truth = nullptr;
+        c->count_dev = nullptr;
+        return rc;
+    }
+    if (!info_hat) {
+        if ((rc = c->ctx->mc_hat.reserve(B * c->Kw * 4))) return rc;
+        info_hat = c->ctx->mc_hat.as<uint32_t>();
+    }
+    if ((rc = launch_sc_decode(c, llr, dtype, info_hat, nullptr, nullptr, B, flags))) return rc;
+    return launch_count_errors(c, info, info_hat, B, counters, nbits);
+}
+
+extern "C" int polar_sc_decode_count(polar_code *c, const void *llr, int dtype, const uint32_t *info, uint32_t *info_hat, int64_t B,
+                                     int flags, uint64_t *counters)
+{
+    CHECK_COMMON(c, B, POLAR_DEVICE);
+    ARG_TRY(llr && info && counters, "NULL buffer");
+    ARG_TRY(dtype == POLAR_F32 || dtype == POLAR_F64, "dtype must be POLAR_F32 or POLAR_F64");
+    CRC_TRY(c, flags);
+    return sc_decode_count(c, llr, dtype, info, info_hat, B, flags, counters, (flags & POLAR_CRC) ? c->K - c->crc_w : c->K);
+}
+
 extern "C" int polar_mc_run(polar_code *c, int decoder, int L, int dtype, int flags, double N0, uint64_t seed,
                             uint64_t frame0, int64_t nframes, uint64_t counters[3])
 {
@@ -878,9 +911,11 @@ extern "C" int polar_mc_run(polar_code *c, int decoder, int L, int dtype, int fl
         if (rc) return rc;
         HIP_TRY(hipEventRecord(ctx->gen_done[b], ctx->gen_stream));
         HIP_TRY(hipStreamWaitEvent(main_stream, ctx->gen_done[b], 0));
-        if (decoder == POLAR_DEC_SC)
-            rc = launch_sc_decode(c, llr_b[b], dtype, ctx->mc_hat.as<uint32_t>(), nullptr, nullptr, nb, flags);
-        else if (decoder == POLAR_DEC_PBF)
+        if (decoder == POLAR_DEC_SC) {
+            if ((rc = sc_decode_count(c, llr_b[b], dtype, info_b[b], nullptr, nb, flags, dcnt, c->K))) return rc;
+            HIP_TRY(hipEventRecord(ctx->dec_done[b], main_stream));
+            continue;
+        } else if (decoder == POLAR_DEC_PBF)
             rc = pbf_device(c, llr_b[b], dtype, L, ctx->mc_hat.as<uint32_t>(), nullptr, nullptr, nullptr, nb);
         else
             rc = launch_scl_decode(c, llr_b[b], dtype, L, ctx->mc_hat.as<uint32_t>(), nullptr, nullptr, nb, crc,

@@ -103,6 +103,11 @@ struct polar_code {
     double *d_sqrt_mu = nullptr;
     int nS0 = 0, maxS = 0;
     bool have_mu = false, have_crit = false;
+    // set around a launch by polar_sc_decode_count: the register SC kernels then compare with the transmitted
+    // words (first count_nbits bits of each) and add to count_dev[3] instead of leaving that to a second kernel
+    const uint32_t *count_truth = nullptr;
+    int count_nbits = 0;
+    uint64_t *count_dev = nullptr;
     // decoder compiled at run time for this rate profile (polar_code_specialize), or null
     hipModule_t static_mod = nullptr;
     hipFunction_t static_fn = nullptr;

@@ -108,8 +108,10 @@ int launch_sc_static(polar_code *c, const void *llr, uint32_t *info_hat, int64_t
     const void *a_asl = c->d_Asl;
     void *a_out = info_hat;
     long long a_B = (long long)B;
-    int a_K = c->K, a_Kw = c->Kw;
-    void *args[] = {&a_llr, &a_asl, &a_out, &a_B, &a_K, &a_Kw};
+    int a_K = c->K, a_Kw = c->Kw, a_nbits = c->count_nbits;
+    const void *a_truth = c->count_truth;
+    void *a_cnt = c->count_dev;
+    void *args[] = {&a_llr, &a_asl, &a_out, &a_B, &a_K, &a_Kw, &a_truth, &a_nbits, &a_cnt};
     LaunchTimer tm(ctx);
     HIP_TRY(hipModuleLaunchKernel(c->static_fn, (unsigned)grid, 1, 1, 64, 1, 1, 0, ctx->stream, args, nullptr));
     float ms = tm.stop();

@@ -237,3 +237,37 @@ def test_sc_specialised_kernel_equals_generic(monkeypatch, N, K):
 
 def n0_of(snr_db, rate):
     return 1.0 / (rate * 10 ** (snr_db / 10))
+
+
+@pytest.mark.parametrize("N,K,dtype", [(1024, 512, np.float32), (256, 77, np.float32), (64, 33, np.float32), (1024, 512, np.float64), (2048, 1000, np.float32)])
+def test_sc_decode_count_fused_equals_two_kernels(N, K, dtype):
+    """polar_sc_decode_count (comparison inside the decoder's output stage where the register kernels apply)
+    against decode followed by polar_count_errors, generic and specialised kernels, with and without storing."""
+    import torch
+
+    mask = pcf.degaBuild(N, K, 2.0)
+    code = _native.Code(_native.default_ctx(), mask)
+    B = 30001
+    dev = torch.device("cuda:0")
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    llr = torch.empty((B, N), dtype=tdt, device=dev)
+    info = torch.zeros((B, code.Kw), dtype=torch.int32, device=dev)
+    code.gen_frames_dev(info.data_ptr(), llr.data_ptr(), dtype, n0_of(1.5, K / N), 3, 0, B)
+    hat = torch.zeros_like(info)
+    ref = torch.zeros(3, dtype=torch.int64, device=dev)
+    code.sc_decode_dev(llr.data_ptr(), dtype, hat.data_ptr(), B, fast=True)
+    code.count_errors_dev(info.data_ptr(), hat.data_ptr(), B, ref.data_ptr())
+    code.ctx.sync()
+    assert 0 < ref[1] < B
+    for spec in ([False, True] if (dtype == np.float32 and N <= 1024) else [False]):
+        if spec:
+            code.specialize()
+        for store in (True, False):
+            got = torch.zeros(3, dtype=torch.int64, device=dev)
+            hat2 = torch.zeros_like(info)
+            code.sc_decode_count_dev(llr.data_ptr(), dtype, info.data_ptr(), B, got.data_ptr(), fast=True,
+                                     info_hat_ptr=hat2.data_ptr() if store else None)
+            code.ctx.sync()
+            assert got.cpu().tolist() == ref.cpu().tolist(), (spec, store)
+            if store:
+                assert torch.equal(hat2, hat)
