@@ -4,7 +4,7 @@
 python bench.py --gpus N --steps K --warmup W
   N = 1: run directly.  N > 1: launched by torch.distributed.run, one rank per GPU.
 
-Workload (BASELINE.json configs[1]): Polar(1024,512) `dega` code, SC decoding of 10^7 frames per GPU,
+Workload (the configuration the headline metric is quoted on): Polar(1024,512) `dega` code, SC decoding of 10^7 frames per GPU,
 BPSK-AWGN at Eb/N0 = 2 dB, fp32 LLRs already resident in HBM (generated on the device by the library's
 Philox channel before the timed region).  A step = one pass of the decoder over the whole batch
 (decode + extract information bits + count errors); with N > 1 every rank decodes its own 10^7 frames
