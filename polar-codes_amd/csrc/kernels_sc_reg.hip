@@ -80,10 +80,10 @@ __global__ void __launch_bounds__(64, 4) sc_reg_kernel(const T *__restrict__ llr
                                                     int K, int Kw, const uint32_t *__restrict__ truth, int nbits,
                                                     unsigned long long *__restrict__ counters)
 {
-    __shared__ uint32_t stage[4 * 16 * 2];  // per frame: 16 lanes x 64-bit slice of u_hat
+    __shared__ __attribute__((aligned(32))) uint32_t stage[SC_STAGE_WORDS];  // per frame: 16 lanes x 64-bit slice of u_hat
     constexpr int N = 1 << NLOG;
-    __shared__ uint32_t asl_s[N];           // the gather table of the output stage
-    for (int k = threadIdx.x; k < K; k += 64) asl_s[k] = Asl[k];
+    __shared__ uint32_t asl_s[GatherShape<NLOG>::WORDS];  // the gather table of the output stage
+    for (int k = threadIdx.x; k < GatherShape<NLOG>::WORDS; k += 64) asl_s[k] = Asl[k];
     wave_sync();
     const int lane = threadIdx.x;
     const int grp = lane >> 4;
@@ -177,7 +177,7 @@ template <typename T, int NLOG, bool FAST> static int launch_reg_t(polar_code *c
     snprintf(c->last.kernel, sizeof(c->last.kernel), "sc_reg_kernel<%s,%d>%s", sizeof(T) == 4 ? "float" : "double", NLOG,
              FAST ? "/fast" : "");
     c->last.lanes_per_frame = 16;
-    c->last.lds_bytes_per_block = 512 + 4 * c->N;
+    c->last.lds_bytes_per_block = 4 * (SC_STAGE_WORDS + GatherShape<NLOG>::WORDS);
     c->last.block_threads = 64;
     c->last.grid_blocks = (int)grid;
     c->last.last_ms = ms;

@@ -98,9 +98,73 @@ template <int NW> struct StaticProfile {
     constexpr uint32_t mask16(int idx) const { return (w[idx >> 1] >> (16 * (idx & 1))) & 0xFFFFu; }
 };
 
+// Decoder state of the specialised kernel.  The LLR slice is that of RegDec; the partial sums have one register
+// per level and plane, X[l - 4][plane] for a node of level l (4 <= l < NLOG), element j of the lane's slice at bit
+// 31 - j: a 16-leaf node delivers 0 / 0x80000000, which g applies with one exclusive-or, and combining two
+// children is (xl ^ xr) | (xr >> c) with nothing to clear or to insert, since which register a node writes is
+// known when the kernel is compiled.
+template <int NLOG, int KEEP = 0> struct StaticDec {
+    static constexpr int S = 1 << (NLOG - 4);
+    float R[S];
+    float CA[KEEP > 0 ? KEEP : 1], CB[KEEP > 0 ? KEEP : 1];
+    uint32_t X[NLOG - 4][2];
+    ps_t root;  // element j at bit j, as the output stage takes it
+
+    template <int LEV, bool IS_G> __device__ __forceinline__ void step(const float *chan_lane)
+    {
+        constexpr int c = 1 << (LEV - 5);
+#pragma unroll
+        for (int j = 0; j < c; j++) {
+            float a, b;
+            if constexpr (LEV == NLOG) {
+                if (IS_G && j < KEEP) {
+                    a = CA[j];
+                    b = CB[j];
+                } else {
+                    a = chan_lane[16 * j];
+                    b = chan_lane[16 * (j + c)];
+                    if (!IS_G && j < KEEP) {
+                        CA[j] = a;
+                        CB[j] = b;
+                    }
+                }
+            } else {
+                a = R[2 * c + j];
+                b = R[3 * c + j];
+            }
+            if constexpr (IS_G) {
+                const uint32_t sgn = (X[LEV - 5][0] << j) & 0x80000000u;
+                R[c + j] = b + __uint_as_float(__float_as_uint(a) ^ sgn);
+            } else {
+                R[c + j] = f_fast(a, b);
+            }
+        }
+    }
+    template <int LEV> __device__ __forceinline__ void combine(int plane)
+    {
+        constexpr int c = 1 << (LEV - 5);  // elements per child
+        const uint32_t xl = X[LEV - 5][0], xr = X[LEV - 5][1];
+        if constexpr (LEV == NLOG) {
+            if constexpr (c == 32) root = (ps_t)__builtin_bitreverse32(xl ^ xr) | ((ps_t)__builtin_bitreverse32(xr) << 32);
+            else root = (ps_t)__builtin_bitreverse32((xl ^ xr) | (xr >> c));
+        } else {
+            X[LEV - 4][plane] = (xl ^ xr) | (xr >> c);
+        }
+    }
+    template <int LEV> __device__ __forceinline__ void rate0(int plane) { X[LEV - 4][plane] = 0u; }
+    template <int LEV> __device__ __forceinline__ void rate1(int plane)
+    {
+        constexpr int c = 1 << (LEV - 4);
+        uint32_t x = 0;
+#pragma unroll
+        for (int j = 0; j < c; j++) x |= (R[c + j] < 0.0f) ? (0x80000000u >> j) : 0u;
+        X[LEV - 4][plane] = x;
+    }
+};
+
 // Node idx of level LEV (>= 5), not all-frozen and not all-information; PLANE = 0 left child, 1 right child.
-template <typename P, int LEV, int IDX, int PLANE, int NLOG, int KEEP, typename T>
-__device__ __forceinline__ void decode_static(RegDec<T, NLOG, KEEP> &d, const T *chan_lane, const RowConst &rc)
+template <typename P, int LEV, int IDX, int PLANE, int NLOG, int KEEP>
+__device__ __forceinline__ void decode_static(StaticDec<NLOG, KEEP> &d, const float *chan_lane, const RowConst &rc)
 {
     constexpr auto prof = P::value();  // StaticProfile<N/32>
     constexpr int full = 1 << (LEV - 1);
@@ -110,36 +174,30 @@ __device__ __forceinline__ void decode_static(RegDec<T, NLOG, KEEP> &d, const T 
         d.template rate0<LEV - 1>(0);
     } else {
         d.template step<LEV, false>(chan_lane);
-        if constexpr (nl == full) {
-            d.template rate1<LEV - 1>(0);
-        } else if constexpr (LEV - 1 == 4) {
-            const uint32_t x = sub_node_c<16, prof.mask16(2 * IDX)>(d.R[1], rc);
-            d.ps0 = (d.ps0 & ~(ps_t)2) | ((ps_t)x << 1);
-        } else {
-            decode_static<P, LEV - 1, 2 * IDX, 0, NLOG, KEEP>(d, chan_lane, rc);
-        }
+        if constexpr (nl == full) d.template rate1<LEV - 1>(0);
+        else if constexpr (LEV - 1 == 4) d.X[0][0] = sub_node_s<16, prof.mask16(2 * IDX)>(d.R[1], rc);
+        else decode_static<P, LEV - 1, 2 * IDX, 0, NLOG, KEEP>(d, chan_lane, rc);
     }
     // right child
     if constexpr (nr == 0) {
         d.template rate0<LEV - 1>(1);
     } else {
         d.template step<LEV, true>(chan_lane);
-        if constexpr (nr == full) {
-            d.template rate1<LEV - 1>(1);
-        } else if constexpr (LEV - 1 == 4) {
-            const uint32_t x = sub_node_c<16, prof.mask16(2 * IDX + 1)>(d.R[1], rc);
-            d.ps1 = (d.ps1 & ~(ps_t)2) | ((ps_t)x << 1);
-        } else {
-            decode_static<P, LEV - 1, 2 * IDX + 1, 1, NLOG, KEEP>(d, chan_lane, rc);
-        }
+        if constexpr (nr == full) d.template rate1<LEV - 1>(1);
+        else if constexpr (LEV - 1 == 4) d.X[0][1] = sub_node_s<16, prof.mask16(2 * IDX + 1)>(d.R[1], rc);
+        else decode_static<P, LEV - 1, 2 * IDX + 1, 1, NLOG, KEEP>(d, chan_lane, rc);
     }
     d.template combine<LEV>(PLANE);
 }
 
-// Output stage shared with sc_reg_kernel: u_hat = x_hat F^{(x)n} on the sliced layout, then the information
-// bits gathered through LDS (stage: 128 words per wavefront) and stored as whole words.  Asl is the gather table
-// (one word per information bit); the kernels keep it in LDS: a global load per gathered bit would put a memory
-// round trip into every iteration of the packing loop.
+// Output stage shared with sc_reg_kernel: u_hat = x_hat F^{(x)n} on the sliced layout, staged in LDS, then lane `sub` of the frame's row assembles output words sub and sub + 16 on its own, one staged bit
+// per step, and the words leave as contiguous stores.  Asl is the gather table in LDS, [bit i][word w] with
+// GATHER_TW words per row: lanes of a row read neighbouring entries, the four rows the same ones.
+constexpr int SC_STAGE_WORDS = 256;  // per wavefront: 32 words per frame, one frame's word every 32 bytes
+template <int NLOG> struct GatherShape {
+    static constexpr int TW = (NLOG >= 10) ? 32 : 16;  // words per table row (>= 16: every lane has an entry)
+    static constexpr int WORDS = 32 * TW;
+};
 // Error counting fused into the output stage: per-lane running sums of bit errors, frame errors and frames
 // (only the first lane of each frame's row counts), added to the global counters once per wavefront.
 struct ErrAcc {
@@ -162,43 +220,60 @@ __device__ __forceinline__ void sc_reg_epilogue(ps_t root, uint32_t *stage, cons
                                                 const uint32_t *__restrict__ truth = nullptr, int nbits = 0, ErrAcc *acc = nullptr)
 {
     const int grp = lane >> 4, sub = lane & 15;
-    ps_t u = root;
-    // stages 4 .. NLOG-1 pair (j, j + 2^(s-4)) inside a lane
-    if constexpr (NLOG > 4) u ^= (u >> 1) & 0x5555555555555555ull;
-    if constexpr (NLOG > 5) u ^= (u >> 2) & 0x3333333333333333ull;
-    if constexpr (NLOG > 6) u ^= (u >> 4) & 0x0F0F0F0F0F0F0F0Full;
-    if constexpr (NLOG > 7) u ^= (u >> 8) & 0x00FF00FF00FF00FFull;
-    if constexpr (NLOG > 8) u ^= (u >> 16) & 0x0000FFFF0000FFFFull;
-    if constexpr (NLOG > 9) u ^= (u >> 32) & 0x00000000FFFFFFFFull;
-    // stages 0 .. 3 pair lanes (l, l + 2^s) of the row: row_shl:n makes lane i read lane i + n
+    uint32_t lo = (uint32_t)root, hi = (uint32_t)(root >> 32);
+    // stages 4 .. NLOG-1 pair (j, j + 2^(s-4)) inside a lane (hi is zero below N = 1024)
+    if constexpr (NLOG > 9) lo ^= hi;
+    if constexpr (NLOG > 4) lo ^= (lo >> 1) & 0x55555555u;
+    if constexpr (NLOG > 5) lo ^= (lo >> 2) & 0x33333333u;
+    if constexpr (NLOG > 6) lo ^= (lo >> 4) & 0x0F0F0F0Fu;
+    if constexpr (NLOG > 7) lo ^= (lo >> 8) & 0x00FF00FFu;
+    if constexpr (NLOG > 8) lo ^= (lo >> 16) & 0x0000FFFFu;
+    if constexpr (NLOG > 9) {
+        hi ^= (hi >> 1) & 0x55555555u;
+        hi ^= (hi >> 2) & 0x33333333u;
+        hi ^= (hi >> 4) & 0x0F0F0F0Fu;
+        hi ^= (hi >> 8) & 0x00FF00FFu;
+        hi ^= (hi >> 16) & 0x0000FFFFu;
+    }
+    // stages 0 .. 3 pair lanes (l, l + 2^s) of the row; the lower lane of a pair takes the upper one's word.  Inside
+    // a quad the word is masked to the upper lanes before the exchange; across quads the exchange itself is limited
+    // to the banks (quads) of the lower lanes.
     {
-        uint32_t lo = (uint32_t)u, hi = (uint32_t)(u >> 32);
-        uint32_t t;
-        t = dpp_mov_u32<0x101>(lo); lo ^= (sub & 1) ? 0u : t; t = dpp_mov_u32<0x101>(hi); hi ^= (sub & 1) ? 0u : t;
-        t = dpp_mov_u32<0x102>(lo); lo ^= (sub & 2) ? 0u : t; t = dpp_mov_u32<0x102>(hi); hi ^= (sub & 2) ? 0u : t;
-        t = dpp_mov_u32<0x104>(lo); lo ^= (sub & 4) ? 0u : t; t = dpp_mov_u32<0x104>(hi); hi ^= (sub & 4) ? 0u : t;
-        t = dpp_mov_u32<0x108>(lo); lo ^= (sub & 8) ? 0u : t; t = dpp_mov_u32<0x108>(hi); hi ^= (sub & 8) ? 0u : t;
-        stage[lane * 2] = lo;
-        stage[lane * 2 + 1] = hi;
+        const uint32_t odd1 = (sub & 1) ? 0xFFFFFFFFu : 0u, odd2 = (sub & 2) ? 0xFFFFFFFFu : 0u;
+        lo ^= dpp_mov_u32<0xB1>(lo & odd1);  // quad_perm:[1,0,3,2]
+        lo ^= dpp_mov_u32<0x4E>(lo & odd2);  // quad_perm:[2,3,0,1]
+        lo ^= dpp_banks_u32<0x104, 0x5>(lo);  // row_shl:4 into quads 0 and 2
+        lo ^= dpp_banks_u32<0x108, 0x3>(lo);  // row_shl:8 into quads 0 and 1
+        if constexpr (NLOG > 9) {
+            hi ^= dpp_mov_u32<0xB1>(hi & odd1);
+            hi ^= dpp_mov_u32<0x4E>(hi & odd2);
+            hi ^= dpp_banks_u32<0x104, 0x5>(hi);
+            hi ^= dpp_banks_u32<0x108, 0x3>(hi);
+        }
+        // staged word w (= 2 lane + half) of the frame in row g at byte 32 w + 4 g: a gather address is then the
+        // table entry with its low five bits (the bit index) replaced
+        stage[16 * sub + grp] = lo;
+        if constexpr (NLOG > 9) stage[16 * sub + 8 + grp] = hi;
     }
     wave_sync();
     if (info_hat || truth) {
-        const uint32_t *mine = stage + grp * 32;
-        // lane `sub` keeps output words sub and sub + 16; the frame's words then leave as one
-        // contiguous 64-byte store per 16 words instead of sixteen scattered 4-byte stores
-        uint32_t w_lo = 0, w_hi = 0;
-        pack_bits_group<16>(
-            K, sub, grp,
-            [&](int k) {
-                uint32_t a = Asl[k];  // (lane << 6) | bit
-                return ((mine[(a >> 6) * 2 + ((a >> 5) & 1u)] >> (a & 31u)) & 1u) != 0u;
-            },
-            [&](int wi, uint32_t v) {
-                if ((wi & 15) == sub) {
-                    if (wi < 16) w_lo = v;
-                    else w_hi = v;
-                }
-            });
+        constexpr int TW = GatherShape<NLOG>::TW;
+        const unsigned char *base = reinterpret_cast<const unsigned char *>(stage);
+        const uint32_t goff = (uint32_t)grp << 2;
+        auto gather = [&](int w) {
+            const uint32_t *t = Asl + w;
+            uint32_t acc = 0;
+#pragma unroll
+            for (int i = 0; i < 32; i++) {
+                const uint32_t e = t[i * TW];  // (staged word << 5) | bit
+                const uint32_t word = *reinterpret_cast<const uint32_t *>(base + ((e & ~31u) | goff));
+                acc = __builtin_amdgcn_alignbit(word >> (e & 31u), acc, 1);  // bit i of acc after 32 steps
+            }
+            const int valid = K - 32 * w;  // unused table entries point at bit 0 of the slice
+            return acc & (valid >= 32 ? 0xFFFFFFFFu : (valid <= 0 ? 0u : ((1u << valid) - 1u)));
+        };
+        const uint32_t w_lo = gather(sub);
+        const uint32_t w_hi = (TW > 16 && Kw > 16) ? gather(sub + 16) : 0u;
         if (info_hat && active) {
             uint32_t *dst = info_hat + fc * Kw;
             if (sub < Kw) dst[sub] = w_lo;
@@ -241,8 +316,10 @@ struct PolarStaticProfile {
     }
 };
 
+// Channel pairs per lane that stay in registers between the top-level f and g (the rest is read a second time,
+// mostly from the L2 / Infinity Cache): 16 is what fits beside the decoder state at four wavefronts per SIMD.
 #ifndef POLAR_STATIC_KEEP
-#define POLAR_STATIC_KEEP 0
+#define POLAR_STATIC_KEEP 16
 #endif
 #ifndef POLAR_STATIC_WAVES
 #define POLAR_STATIC_WAVES 4
@@ -252,16 +329,16 @@ extern "C" __global__ void __launch_bounds__(64, POLAR_STATIC_WAVES) sc_static_k
                                                                     const uint32_t *__restrict__ truth, int nbits,
                                                                     unsigned long long *__restrict__ counters)
 {
-    __shared__ uint32_t stage[4 * 16 * 2];
+    __shared__ __attribute__((aligned(32))) uint32_t stage[SC_STAGE_WORDS];
     constexpr int NLOG = POLAR_STATIC_NLOG;
     constexpr int N = 1 << NLOG;
-    __shared__ uint32_t asl_s[N];
-    for (int k = threadIdx.x; k < K; k += 64) asl_s[k] = Asl[k];
+    __shared__ uint32_t asl_s[GatherShape<NLOG>::WORDS];
+    for (int k = threadIdx.x; k < GatherShape<NLOG>::WORDS; k += 64) asl_s[k] = Asl[k];
     wave_sync();
     const int lane = threadIdx.x;
     const int grp = lane >> 4;
     const int sub = lane & 15;
-    RegDec<float, NLOG, POLAR_STATIC_KEEP> d;
+    StaticDec<NLOG, POLAR_STATIC_KEEP> d;
     ErrAcc acc;
     RowConst rc;
 #pragma unroll
@@ -274,8 +351,6 @@ extern "C" __global__ void __launch_bounds__(64, POLAR_STATIC_WAVES) sc_static_k
         const bool active = f < B;
         const long long fc = active ? f : B - 1;
         const float *chan_lane = llr + fc * N + sub;
-        d.ps0 = d.ps1 = 0;
-        d.root = 0;
         decode_static<PolarStaticProfile, NLOG, 0, 0, NLOG, POLAR_STATIC_KEEP>(d, chan_lane, rc);
         sc_reg_epilogue<NLOG>(d.root, stage, asl_s, info_hat, fc, active, lane, K, Kw, truth, nbits, &acc);
     }

@@ -198,8 +198,18 @@ extern "C" int polar_code_create(polar_ctx *ctx, int N, const uint8_t *mask, pol
     c->sched[1] = build_schedule(c->mask.data(), N, true);
     c->sched[2] = build_schedule(c->mask.data(), N, false, true);
     c->sched[3] = build_schedule(c->mask.data(), N, true, true);
+    // Gather table of the register SC kernels' output stage: entry [i * TW + w] locates information bit 32 w + i
+    // in the frame's staged u_hat (element k in lane k mod 16, bit k / 16 of the lane's 64-bit slice, stored as
+    // words 2 lane, 2 lane + 1): (word << 5) | bit.  TW = words per row; unused entries stay zero.
     std::vector<uint32_t> Asl;
-    for (uint32_t pos : A) Asl.push_back(((pos & 15u) << 6) | (pos >> 4));
+    if (N <= 1024) {
+        const int TW = std::max(N / 32, 16);
+        Asl.assign((size_t)32 * TW, 0u);
+        for (size_t k = 0; k < A.size(); k++) {
+            const uint32_t pos = A[k], lane = pos & 15u, j = pos >> 4;
+            Asl[(k & 31) * TW + (k >> 5)] = ((2u * lane + (j >> 5)) << 5) | (j & 31u);
+        }
+    }
     std::vector<uint32_t> Asl8;
     for (uint32_t pos : A) {
         uint32_t e = pos & 7u, q = e < 4 ? e : 11 - e;

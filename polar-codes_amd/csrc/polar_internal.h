@@ -92,7 +92,7 @@ struct polar_code {
     uint32_t *d_sched[4] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t *d_Asl8 = nullptr;    // same for the 8-lanes-per-path layout: (lane-in-path << 7) | bit
     uint32_t *d_pid16 = nullptr;   // 64 words: compiled-profile number of each 16-leaf node (register SC kernel)
-    uint32_t *d_Asl = nullptr;     // K entries: (lane << 6) | bit of each info position in the sliced layout
+    uint32_t *d_Asl = nullptr;     // gather table of the register SC kernels: [bit i][word w] -> (staged word << 5) | bit
     // CRC (0 = none): generator with leading term, degree, and the two linear maps of the remainder
     uint64_t crc_poly = 0;
     int crc_w = 0;

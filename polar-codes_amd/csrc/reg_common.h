@@ -11,7 +11,7 @@
 // ---- DPP row rotation: lane i of a 16-lane row reads lane (i - R) mod 16 ---------------------------
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float v)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 template <int CTRL> __device__ __forceinline__ double dpp_mov(double v)
 {
@@ -23,6 +23,11 @@ template <int CTRL> __device__ __forceinline__ double dpp_mov(double v)
 template <int CTRL> __device__ __forceinline__ uint32_t dpp_mov_u32(uint32_t v)
 {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+// the exchange limited to the quads named by BANKS (bit q = lanes 4q .. 4q+3 of every row); other lanes get zero
+template <int CTRL, int BANKS> __device__ __forceinline__ uint32_t dpp_banks_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, BANKS, false);
 }
 // partner exchange for a period-P replicated vector: rotate by P/2
 template <int P, typename T> __device__ __forceinline__ T partner(T v)
@@ -162,6 +167,40 @@ template <int P, uint32_t MASK, typename T> __device__ __forceinline__ uint32_t 
             const T t = flip_sign(v, y);
             const T vr = t + partner<P>(t);
             const uint32_t xr = sub_node_c<P / 2, MR>(vr, rc);
+            return xr ^ y;
+        }
+    }
+}
+
+// The compile-time decoder once more (fp32), with decisions and partial sums kept where g needs them: 0 or
+// 0x80000000.  Applying a sum to an LLR is then one exclusive-or, and no 0/1 value is shifted into place.
+__device__ __forceinline__ uint32_t neg31(float v) { return pin(v < 0.0f ? 0x80000000u : 0u); }
+template <int P, uint32_t MASK> __device__ __forceinline__ uint32_t sub_node_s(float v, const RowConst &rc)
+{
+    constexpr uint32_t FULL = (P >= 32) ? 0xFFFFFFFFu : ((1u << P) - 1u), HALF = (1u << (P / 2)) - 1u;
+    constexpr int I = P == 16 ? 0 : P == 8 ? 1 : P == 4 ? 2 : 3;
+    if constexpr (MASK == 0u) {
+        return 0u;
+    } else if constexpr (MASK == FULL) {
+        return neg31(v);
+    } else if constexpr (MASK == (1u << (P - 1))) {
+        float s = v + partner<P>(v);
+        if constexpr (P >= 4) s = s + partner<P / 2>(s);
+        if constexpr (P >= 8) s = s + partner<P / 4>(s);
+        if constexpr (P >= 16) s = s + partner<P / 8>(s);
+        return neg31(s);
+    } else {
+        constexpr uint32_t ML = MASK & HALF, MR = (MASK >> (P / 2)) & HALF;
+        const float o = partner<P>(v);
+        if constexpr (ML == 0u) {
+            return sub_node_s<P / 2, MR>(v + o, rc);
+        } else {
+            const float vl = f_fast(v, o);
+            const uint32_t xl = sub_node_s<P / 2, ML>(vl, rc);
+            const uint32_t y = xl & rc.lowmask[I];
+            const float t = __uint_as_float(__float_as_uint(v) ^ y);
+            const float vr = t + partner<P>(t);
+            const uint32_t xr = sub_node_s<P / 2, MR>(vr, rc);
             return xr ^ y;
         }
     }

@@ -54,6 +54,13 @@ static int compile_static(const uint8_t *mask, int N, const char *arch, std::vec
     code.resize(cs);
     hiprtcGetCode(prog, code.data());
     hiprtcDestroyProgram(&prog);
+    // POLAR_STATIC_DUMP=<file>: keep the code object (llvm-objdump -d shows what the specialisation produced)
+    if (const char *e = getenv("POLAR_STATIC_DUMP")) {
+        if (FILE *fp = fopen(e, "wb")) {
+            fwrite(code.data(), 1, code.size(), fp);
+            fclose(fp);
+        }
+    }
     return POLAR_OK;
 }
 
@@ -117,7 +124,7 @@ int launch_sc_static(polar_code *c, const void *llr, uint32_t *info_hat, int64_t
     float ms = tm.stop();
     snprintf(c->last.kernel, sizeof(c->last.kernel), "sc_static_kernel<%d>", c->n);
     c->last.lanes_per_frame = 16;
-    c->last.lds_bytes_per_block = 512 + 4 * c->N;
+    c->last.lds_bytes_per_block = 4 * (256 + 32 * std::max(c->N / 32, 16));
     c->last.block_threads = 64;
     c->last.grid_blocks = (int)grid;
     c->last.last_ms = ms;
