@@ -65,6 +65,7 @@ template <typename T> __global__ void __launch_bounds__(64) pbf_decode_kernel(PB
     for (int i = 0; i < 4; i++) {
         rc.up[i] = (lane & (8 >> i)) != 0;
         rc.lowmask[i] = rc.up[i] ? 0u : 0xFFFFFFFFu;
+        rc.low31[i] = rc.up[i] ? 0u : 0x80000000u;
     }
 
     for (;;) {

@@ -50,6 +50,7 @@ template <typename T, int G> __global__ void __launch_bounds__(64) sc_decode_ker
     for (int i = 0; i < 4; i++) {
         rc.up[i] = (lane & (8 >> i)) != 0;
         rc.lowmask[i] = rc.up[i] ? 0u : 0xFFFFFFFFu;
+        rc.low31[i] = rc.up[i] ? 0u : 0x80000000u;
     }
 
     for (int64_t f0 = (int64_t)blockIdx.x * FPW; f0 < p.B; f0 += (int64_t)gridDim.x * FPW) {

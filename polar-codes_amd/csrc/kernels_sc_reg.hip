@@ -59,7 +59,7 @@ __device__ __forceinline__ void decode_node(RegDec<T, NLOG> &d, const NodeClasse
                 const uint32_t pid = FAST ? (uint32_t)__builtin_amdgcn_readlane((int)pidv, (int)cidx) : 0u;
                 switch (pid) {
 #define POLAR_CASE16(ID, MASK) \
-    case ID: x = sub_node_c<16, MASK>(d.R[1], rc); break;
+    case ID: x = sub_node_s<16, MASK>(d.R[1], rc) >> 31; break;
                     POLAR_PROFILES16(POLAR_CASE16)
 #undef POLAR_CASE16
                 default: x = sub_node<16, FAST>(d.R[1], m16, rc); break;
@@ -95,6 +95,7 @@ __global__ void __launch_bounds__(64, 4) sc_reg_kernel(const T *__restrict__ llr
     for (int i = 0; i < 4; i++) {
         rc.up[i] = (sub & (8 >> i)) != 0;
         rc.lowmask[i] = rc.up[i] ? 0u : 0xFFFFFFFFu;
+        rc.low31[i] = rc.up[i] ? 0u : 0x80000000u;
     }
     const uint32_t maskv = maskw[(lane & 31) < (N / 32) ? (lane & 31) : 0];
     const uint32_t pidv = pid16[lane < (N / 16) ? lane : 0];

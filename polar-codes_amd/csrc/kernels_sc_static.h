@@ -11,6 +11,7 @@
 #include "reg_common.h"
 
 typedef uint64_t ps_t;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <typename T, int NLOG, int KEEP = 0> struct RegDec {
     static constexpr int S = 1 << (NLOG - 4);  // slice length per lane
@@ -100,7 +101,8 @@ template <int NW> struct StaticProfile {
 
 // Decoder state of the specialised kernel.  The LLR slice is that of RegDec; the partial sums have one register
 // per level and plane, X[l - 4][plane] for a node of level l (4 <= l < NLOG), element j of the lane's slice at bit
-// 31 - j: a 16-leaf node delivers 0 / 0x80000000, which g applies with one exclusive-or, and combining two
+// 31 - j: a 16-leaf node delivers its bit in bit 31 (other bits arbitrary), which g applies with one masked
+// exclusive-or, and combining two
 // children is (xl ^ xr) | (xr >> c) with nothing to clear or to insert, since which register a node writes is
 // known when the kernel is compiled.
 template <int NLOG, int KEEP = 0> struct StaticDec {
@@ -113,9 +115,14 @@ template <int NLOG, int KEEP = 0> struct StaticDec {
     template <int LEV, bool IS_G> __device__ __forceinline__ void step(const float *chan_lane)
     {
         constexpr int c = 1 << (LEV - 5);
-#pragma unroll
-        for (int j = 0; j < c; j++) {
-            float a, b;
+        if constexpr (LEV == NLOG && IS_G) {
+            // the second read of the channel goes through an offset the compiler cannot see is zero: reusing
+            // the values of the first read would keep the whole slice in registers, KEEP decides how much of it is
+            uint32_t zero = 0;
+            asm volatile("" : "+v"(zero));
+            chan_lane += zero;
+        }
+        auto fetch = [&](int j, float &a, float &b) {
             if constexpr (LEV == NLOG) {
                 if (IS_G && j < KEEP) {
                     a = CA[j];
@@ -132,18 +139,41 @@ template <int NLOG, int KEEP = 0> struct StaticDec {
                 a = R[2 * c + j];
                 b = R[3 * c + j];
             }
-            if constexpr (IS_G) {
-                const uint32_t sgn = (X[LEV - 5][0] << j) & 0x80000000u;
-                R[c + j] = b + __uint_as_float(__float_as_uint(a) ^ sgn);
-            } else {
-                R[c + j] = f_fast(a, b);
+        };
+        if constexpr (IS_G && c >= 2) {
+            // two elements per addition (packed fp32 add)
+#pragma unroll
+            for (int j = 0; j < c; j += 2) {
+                float a0, b0, a1, b1;
+                fetch(j, a0, b0);
+                fetch(j + 1, a1, b1);
+                const uint32_t s0 = (X[LEV - 5][0] << j) & 0x80000000u, s1 = (X[LEV - 5][0] << (j + 1)) & 0x80000000u;
+                const f32x2 r = f32x2{b0, b1} + f32x2{__uint_as_float(__float_as_uint(a0) ^ s0), __uint_as_float(__float_as_uint(a1) ^ s1)};
+                R[c + j] = r.x;
+                R[c + j + 1] = r.y;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < c; j++) {
+                float a, b;
+                fetch(j, a, b);
+                if constexpr (IS_G) {
+                    const uint32_t sgn = (X[LEV - 5][0] << j) & 0x80000000u;
+                    R[c + j] = b + __uint_as_float(__float_as_uint(a) ^ sgn);
+                } else {
+                    R[c + j] = f_fast(a, b);
+                }
             }
         }
     }
     template <int LEV> __device__ __forceinline__ void combine(int plane)
     {
         constexpr int c = 1 << (LEV - 5);  // elements per child
-        const uint32_t xl = X[LEV - 5][0], xr = X[LEV - 5][1];
+        uint32_t xl = X[LEV - 5][0], xr = X[LEV - 5][1];
+        if constexpr (LEV == 5) {  // 16-leaf nodes deliver bit 31 only
+            xl &= 0x80000000u;
+            xr &= 0x80000000u;
+        }
         if constexpr (LEV == NLOG) {
             if constexpr (c == 32) root = (ps_t)__builtin_bitreverse32(xl ^ xr) | ((ps_t)__builtin_bitreverse32(xr) << 32);
             else root = (ps_t)__builtin_bitreverse32((xl ^ xr) | (xr >> c));
@@ -155,10 +185,15 @@ template <int NLOG, int KEEP = 0> struct StaticDec {
     template <int LEV> __device__ __forceinline__ void rate1(int plane)
     {
         constexpr int c = 1 << (LEV - 4);
-        uint32_t x = 0;
+        if constexpr (c == 1) {
+            X[0][plane] = decision_word(R[1]);
+        } else {
+            // (x << 1) | decision per element, then the c bits moved to the top: element j at bit 31 - j
+            uint32_t x = 0;
 #pragma unroll
-        for (int j = 0; j < c; j++) x |= (R[c + j] < 0.0f) ? (0x80000000u >> j) : 0u;
-        X[LEV - 4][plane] = x;
+            for (int j = 0; j < c; j++) x = __builtin_amdgcn_alignbit(x, decision_word(R[c + j]), 31);
+            X[LEV - 4][plane] = x << (32 - c);
+        }
     }
 };
 
@@ -345,6 +380,7 @@ extern "C" __global__ void __launch_bounds__(64, POLAR_STATIC_WAVES) sc_static_k
     for (int i = 0; i < 4; i++) {
         rc.up[i] = (sub & (8 >> i)) != 0;
         rc.lowmask[i] = rc.up[i] ? 0u : 0xFFFFFFFFu;
+        rc.low31[i] = rc.up[i] ? 0u : 0x80000000u;
     }
     for (long long f0 = (long long)blockIdx.x * 4; f0 < B; f0 += (long long)gridDim.x * 4) {
         const long long f = f0 + grp;

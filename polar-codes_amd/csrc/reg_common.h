@@ -80,6 +80,7 @@ __device__ __forceinline__ double flip_sign(double v, uint32_t bit)
 // Lane constants of the replicated butterfly: for period P, lanes whose element index is in the upper half.
 struct RowConst {
     uint32_t lowmask[4];  // P = 16, 8, 4, 2: all-ones when (sub & P/2) == 0
+    uint32_t low31[4];    // the same with bit 31 only
     bool up[4];
 };
 
@@ -138,43 +139,13 @@ template <int P, bool SHORT, typename T> __device__ __forceinline__ uint32_t sub
     }
 }
 
-// The same decoder with the rate profile of the node known at compile time: no branch is left.
-template <int P, uint32_t MASK, typename T> __device__ __forceinline__ uint32_t sub_node_c(T v, const RowConst &rc)
-{
-    constexpr uint32_t FULL = (P >= 32) ? 0xFFFFFFFFu : ((1u << P) - 1u), HALF = (1u << (P / 2)) - 1u;
-    constexpr int I = P == 16 ? 0 : P == 8 ? 1 : P == 4 ? 2 : 3;
-    if constexpr (MASK == 0u) {
-        return 0u;
-    } else if constexpr (MASK == FULL) {
-        return pin(v < (T)0 ? 1u : 0u);
-    } else if constexpr (MASK == (1u << (P - 1))) {
-        T s = v + partner<P>(v);
-        if constexpr (P >= 4) s = s + partner<P / 2>(s);
-        if constexpr (P >= 8) s = s + partner<P / 4>(s);
-        if constexpr (P >= 16) s = s + partner<P / 8>(s);
-        return pin(s < (T)0 ? 1u : 0u);
-    } else {
-        constexpr uint32_t ML = MASK & HALF, MR = (MASK >> (P / 2)) & HALF;
-        const T o = partner<P>(v);
-        if constexpr (ML == 0u) {
-            // frozen left half: its partial sums are zero, the right half sees hi + lo
-            const T vr = v + o;
-            return sub_node_c<P / 2, MR>(vr, rc);
-        } else {
-            const T vl = f_fast(v, o);
-            const uint32_t xl = sub_node_c<P / 2, ML>(vl, rc);
-            const uint32_t y = xl & rc.lowmask[I];
-            const T t = flip_sign(v, y);
-            const T vr = t + partner<P>(t);
-            const uint32_t xr = sub_node_c<P / 2, MR>(vr, rc);
-            return xr ^ y;
-        }
-    }
-}
-
-// The compile-time decoder once more (fp32), with decisions and partial sums kept where g needs them: 0 or
-// 0x80000000.  Applying a sum to an LLR is then one exclusive-or, and no 0/1 value is shifted into place.
-__device__ __forceinline__ uint32_t neg31(float v) { return pin(v < 0.0f ? 0x80000000u : 0u); }
+// The same decoder (fp32) with the rate profile of the node known at compile time: no branch is left.  Decisions
+// and partial sums travel in bit 31 of a word, where g needs them (applying a sum to an LLR is one exclusive-or and
+// no 0/1 value is shifted into place); the other 31 bits of the returned word are arbitrary.  A decision is the
+// LLR itself after adding +0, which turns -0 into +0 and changes no other value: bit 31 is then exactly (v < 0).
+// An all-frozen left half needs no f: its sums are zero and the right half sees hi + lo; a node whose last leaf
+// alone carries information is the sum of its LLRs.
+__device__ __forceinline__ uint32_t decision_word(float v) { return __float_as_uint(v + 0.0f); }
 template <int P, uint32_t MASK> __device__ __forceinline__ uint32_t sub_node_s(float v, const RowConst &rc)
 {
     constexpr uint32_t FULL = (P >= 32) ? 0xFFFFFFFFu : ((1u << P) - 1u), HALF = (1u << (P / 2)) - 1u;
@@ -182,13 +153,13 @@ template <int P, uint32_t MASK> __device__ __forceinline__ uint32_t sub_node_s(f
     if constexpr (MASK == 0u) {
         return 0u;
     } else if constexpr (MASK == FULL) {
-        return neg31(v);
+        return decision_word(v);
     } else if constexpr (MASK == (1u << (P - 1))) {
         float s = v + partner<P>(v);
         if constexpr (P >= 4) s = s + partner<P / 2>(s);
         if constexpr (P >= 8) s = s + partner<P / 4>(s);
         if constexpr (P >= 16) s = s + partner<P / 8>(s);
-        return neg31(s);
+        return decision_word(s);
     } else {
         constexpr uint32_t ML = MASK & HALF, MR = (MASK >> (P / 2)) & HALF;
         const float o = partner<P>(v);
@@ -197,7 +168,7 @@ template <int P, uint32_t MASK> __device__ __forceinline__ uint32_t sub_node_s(f
         } else {
             const float vl = f_fast(v, o);
             const uint32_t xl = sub_node_s<P / 2, ML>(vl, rc);
-            const uint32_t y = xl & rc.lowmask[I];
+            const uint32_t y = xl & rc.low31[I];
             const float t = __uint_as_float(__float_as_uint(v) ^ y);
             const float vr = t + partner<P>(t);
             const uint32_t xr = sub_node_s<P / 2, MR>(vr, rc);
