@@ -244,15 +244,17 @@ __global__ void __launch_bounds__(BLOCK) gen_frames_kernel(uint32_t *__restrict_
     }
     if (info_out)
         for (int idx = threadIdx.x; idx < nfr * Kw; idx += BLOCK) info_out[f0 * Kw + idx] = iw[idx];
+    // N is a power of two, so words per frame and Philox blocks per frame are too: shifts, not divisions
+    const int nwlog = n > 5 ? n - 5 : 0, qlog = n > 2 ? n - 2 : 0;
     int nwords = nfr * Nw;
     for (int idx = threadIdx.x; idx < nwords; idx += BLOCK) {
-        int fl = idx / Nw, m = idx - fl * Nw;
+        int fl = idx >> nwlog, m = idx & (Nw - 1);
         xw[idx] = butterfly_in_word(rate_profile_word(iw + fl * Kw, maskw[m], rank[m]), n);
     }
     butterfly_cross_words(xw, nwords, Nw, n);
     int q = (N + 3) / 4;
     for (int idx = threadIdx.x; idx < nfr * q; idx += BLOCK) {
-        int fl = idx / q, j = idx - fl * q;
+        int fl = idx >> qlog, j = idx & (q - 1);
         uint32_t bits = (xw[fl * Nw + (j >> 3)] >> ((j & 7) * 4)) & 0xFu;
         T o[4];
         llr4<T>(seed, frame0 + (uint64_t)(f0 + fl), (uint32_t)j, bits, sigma, gain, o);
