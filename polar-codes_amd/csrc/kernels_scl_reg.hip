@@ -234,6 +234,35 @@ template <int NLOG> struct SclReg {
         return b;
     }
 
+    // A node of P leaves (2, 4 or 8), all frozen: nothing forks and every partial sum is zero, so the P decision LLRs
+    // are computed side by side (after the exchange for period Q the lanes of the lower half hold the left child's
+    // element, the others the right child's: lane element e ends with the LLR of leaf e mod P), the P metric
+    // terms in one go, and the path metric takes them in leaf order, as the leaf-by-leaf walk would.
+    template <int P> __device__ __forceinline__ void frozen_node(float v, const LaneConst &lc)
+    {
+        float x = v;
+        if constexpr (P >= 8) {
+            const float o = partner8<8>(x);
+            x = lc.up[0] ? x + o : f_fast(x, o);
+        }
+        if constexpr (P >= 4) {
+            const float o = partner8<4>(x);
+            x = lc.up[1] ? x + o : f_fast(x, o);
+        }
+        {
+            const float o = partner8<2>(x);
+            x = lc.up[2] ? x + o : f_fast(x, o);
+        }
+        const float m = branch_metric_fast(x, 0u);
+        float t[P];
+#pragma unroll
+        for (int i = 0; i < P; i++) t[i] = bperm_f(m, (lc.lane & ~7) + (i < 4 ? i : 11 - i));  // the lane whose element is i
+        float pm = st.pm;
+#pragma unroll
+        for (int i = 0; i < P; i++) pm += t[i];
+        st.pm = pm;
+    }
+
     // A node of P leaves inside the 8-leaf subtree; v replicated with period P over the path's lanes.
     template <int P, uint32_t LIVE = 0u>
     __device__ __forceinline__ uint32_t sub(float v, uint32_t mask, const LaneConst &lc, uint32_t *surv)
@@ -241,6 +270,10 @@ template <int NLOG> struct SclReg {
         if constexpr (P == 1) {
             return leaf<LIVE>(v, mask & 1u, lc, surv);
         } else {
+            if (mask == 0u) {  // wave-uniform: the rate profile is the same for every path
+                frozen_node<P>(v, lc);
+                return 0u;
+            }
             constexpr int I = P == 8 ? 0 : P == 4 ? 1 : 2;
             constexpr uint32_t HALF = (1u << (P / 2)) - 1u;
             const float o = partner8<P>(v);
