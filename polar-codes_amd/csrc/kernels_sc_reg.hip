@@ -76,13 +76,13 @@ __device__ __forceinline__ void decode_node(RegDec<T, NLOG> &d, const NodeClasse
 
 template <typename T, int NLOG, bool FAST>
 __global__ void __launch_bounds__(64, 4) sc_reg_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, NodeClasses nc,
-                                                    const uint32_t *__restrict__ pid16, const uint32_t *__restrict__ Asl, uint32_t *__restrict__ info_hat, int64_t B,
+                                                    const uint32_t *__restrict__ pid16, const uint16_t *__restrict__ Asl, uint32_t *__restrict__ info_hat, int64_t B,
                                                     int K, int Kw, const uint32_t *__restrict__ truth, int nbits,
                                                     unsigned long long *__restrict__ counters)
 {
     __shared__ __attribute__((aligned(32))) uint32_t stage[SC_STAGE_WORDS];  // per frame: 16 lanes x 64-bit slice of u_hat
     constexpr int N = 1 << NLOG;
-    __shared__ uint32_t asl_s[GatherShape<NLOG>::WORDS];  // the gather table of the output stage
+    __shared__ uint16_t asl_s[GatherShape<NLOG>::WORDS];  // the gather table of the output stage
     for (int k = threadIdx.x; k < GatherShape<NLOG>::WORDS; k += 64) asl_s[k] = Asl[k];
     wave_sync();
     const int lane = threadIdx.x;
@@ -171,14 +171,14 @@ template <typename T, int NLOG, bool FAST> static int launch_reg_t(polar_code *c
     int64_t grid = std::min<int64_t>(need, (int64_t)ctx->num_cus * occ * 8);
     LaunchTimer tm(ctx);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), pad, ctx->stream, (const T *)llr, (const uint32_t *)c->d_maskw, nc,
-                       (const uint32_t *)c->d_pid16, (const uint32_t *)c->d_Asl, info_hat, B, c->K, c->Kw, c->count_truth, c->count_nbits,
+                       (const uint32_t *)c->d_pid16, (const uint16_t *)c->d_Asl, info_hat, B, c->K, c->Kw, c->count_truth, c->count_nbits,
                        (unsigned long long *)c->count_dev);
     HIP_TRY(hipGetLastError());
     float ms = tm.stop();
     snprintf(c->last.kernel, sizeof(c->last.kernel), "sc_reg_kernel<%s,%d>%s", sizeof(T) == 4 ? "float" : "double", NLOG,
              FAST ? "/fast" : "");
     c->last.lanes_per_frame = 16;
-    c->last.lds_bytes_per_block = 4 * (SC_STAGE_WORDS + GatherShape<NLOG>::WORDS);
+    c->last.lds_bytes_per_block = 4 * SC_STAGE_WORDS + 2 * GatherShape<NLOG>::WORDS;
     c->last.block_threads = 64;
     c->last.grid_blocks = (int)grid;
     c->last.last_ms = ms;

@@ -105,10 +105,14 @@ template <int NW> struct StaticProfile {
 // exclusive-or, and combining two
 // children is (xl ^ xr) | (xr >> c) with nothing to clear or to insert, since which register a node writes is
 // known when the kernel is compiled.
-template <int NLOG, int KEEP = 0> struct StaticDec {
+// Of the lane's 2^(NLOG-5) channel pairs the first KEEP stay in registers between the top-level f and g, the next KL in
+// LDS (kept[k * 64], k = 2 pair, 2 pair + 1: the wavefront's region, one column per lane); the rest is read again.
+template <int NLOG_, int KEEP = 0, int KL = 0> struct StaticDec {
+    static constexpr int NLOG = NLOG_;
     static constexpr int S = 1 << (NLOG - 4);
     float R[S];
     float CA[KEEP > 0 ? KEEP : 1], CB[KEEP > 0 ? KEEP : 1];
+    float *kept;
     uint32_t X[NLOG - 4][2];
     ps_t root;  // element j at bit j, as the output stage takes it
 
@@ -127,12 +131,18 @@ template <int NLOG, int KEEP = 0> struct StaticDec {
                 if (IS_G && j < KEEP) {
                     a = CA[j];
                     b = CB[j];
+                } else if (IS_G && j < KEEP + KL) {
+                    a = kept[(2 * (j - KEEP)) * 64];
+                    b = kept[(2 * (j - KEEP) + 1) * 64];
                 } else {
                     a = chan_lane[16 * j];
                     b = chan_lane[16 * (j + c)];
                     if (!IS_G && j < KEEP) {
                         CA[j] = a;
                         CB[j] = b;
+                    } else if (!IS_G && j < KEEP + KL) {
+                        kept[(2 * (j - KEEP)) * 64] = a;
+                        kept[(2 * (j - KEEP) + 1) * 64] = b;
                     }
                 }
             } else {
@@ -198,8 +208,8 @@ template <int NLOG, int KEEP = 0> struct StaticDec {
 };
 
 // Node idx of level LEV (>= 5), not all-frozen and not all-information; PLANE = 0 left child, 1 right child.
-template <typename P, int LEV, int IDX, int PLANE, int NLOG, int KEEP>
-__device__ __forceinline__ void decode_static(StaticDec<NLOG, KEEP> &d, const float *chan_lane, const RowConst &rc)
+template <typename P, int LEV, int IDX, int PLANE, typename Dec>
+__device__ __forceinline__ void decode_static(Dec &d, const float *chan_lane, const RowConst &rc)
 {
     constexpr auto prof = P::value();  // StaticProfile<N/32>
     constexpr int full = 1 << (LEV - 1);
@@ -211,7 +221,7 @@ __device__ __forceinline__ void decode_static(StaticDec<NLOG, KEEP> &d, const fl
         d.template step<LEV, false>(chan_lane);
         if constexpr (nl == full) d.template rate1<LEV - 1>(0);
         else if constexpr (LEV - 1 == 4) d.X[0][0] = sub_node_s<16, prof.mask16(2 * IDX)>(d.R[1], rc);
-        else decode_static<P, LEV - 1, 2 * IDX, 0, NLOG, KEEP>(d, chan_lane, rc);
+        else decode_static<P, LEV - 1, 2 * IDX, 0>(d, chan_lane, rc);
     }
     // right child
     if constexpr (nr == 0) {
@@ -220,7 +230,7 @@ __device__ __forceinline__ void decode_static(StaticDec<NLOG, KEEP> &d, const fl
         d.template step<LEV, true>(chan_lane);
         if constexpr (nr == full) d.template rate1<LEV - 1>(1);
         else if constexpr (LEV - 1 == 4) d.X[0][1] = sub_node_s<16, prof.mask16(2 * IDX + 1)>(d.R[1], rc);
-        else decode_static<P, LEV - 1, 2 * IDX + 1, 1, NLOG, KEEP>(d, chan_lane, rc);
+        else decode_static<P, LEV - 1, 2 * IDX + 1, 1>(d, chan_lane, rc);
     }
     d.template combine<LEV>(PLANE);
 }
@@ -229,6 +239,7 @@ __device__ __forceinline__ void decode_static(StaticDec<NLOG, KEEP> &d, const fl
 // per step, and the words leave as contiguous stores.  Asl is the gather table in LDS, [bit i][word w] with
 // GATHER_TW words per row: lanes of a row read neighbouring entries, the four rows the same ones.
 constexpr int SC_STAGE_WORDS = 256;  // per wavefront: 32 words per frame, one frame's word every 32 bytes
+constexpr int SC_STATIC_WAVES = 4;   // wavefronts per workgroup of the specialised kernel
 template <int NLOG> struct GatherShape {
     static constexpr int TW = (NLOG >= 10) ? 32 : 16;  // words per table row (>= 16: every lane has an entry)
     static constexpr int WORDS = 32 * TW;
@@ -250,7 +261,7 @@ __device__ __forceinline__ void err_acc_flush(const ErrAcc &a, unsigned long lon
 // truth (packed [B x Kw], or NULL): the transmitted information words; their first nbits bits are compared with the
 // decoded ones and the result goes into acc.  info_hat may then be NULL (nothing is stored).
 template <int NLOG>
-__device__ __forceinline__ void sc_reg_epilogue(ps_t root, uint32_t *stage, const uint32_t *Asl, uint32_t *__restrict__ info_hat,
+__device__ __forceinline__ void sc_reg_epilogue(ps_t root, uint32_t *stage, const uint16_t *Asl, uint32_t *__restrict__ info_hat,
                                                 int64_t fc, bool active, int lane, int K, int Kw,
                                                 const uint32_t *__restrict__ truth = nullptr, int nbits = 0, ErrAcc *acc = nullptr)
 {
@@ -296,7 +307,7 @@ __device__ __forceinline__ void sc_reg_epilogue(ps_t root, uint32_t *stage, cons
         const unsigned char *base = reinterpret_cast<const unsigned char *>(stage);
         const uint32_t goff = (uint32_t)grp << 2;
         auto gather = [&](int w) {
-            const uint32_t *t = Asl + w;
+            const uint16_t *t = Asl + w;
             uint32_t acc = 0;
 #pragma unroll
             for (int i = 0; i < 32; i++) {
@@ -351,29 +362,44 @@ struct PolarStaticProfile {
     }
 };
 
-// Channel pairs per lane that stay in registers between the top-level f and g (the rest is read a second time,
-// mostly from the L2 / Infinity Cache): 16 is what fits beside the decoder state at four wavefronts per SIMD.
+// Channel pairs per lane that stay on chip between the top-level f and g: POLAR_STATIC_KEEP in registers (16 is what
+// fits beside the decoder state at four wavefronts per SIMD) and up to POLAR_STATIC_KEEP_LDS more in LDS; what is
+// left is read a second time, mostly from the L2 / Infinity Cache.
 #ifndef POLAR_STATIC_KEEP
 #define POLAR_STATIC_KEEP 16
+#endif
+#ifndef POLAR_STATIC_KEEP_LDS
+#define POLAR_STATIC_KEEP_LDS 16
 #endif
 #ifndef POLAR_STATIC_WAVES
 #define POLAR_STATIC_WAVES 4
 #endif
-extern "C" __global__ void __launch_bounds__(64, POLAR_STATIC_WAVES) sc_static_kernel(const float *__restrict__ llr, const uint32_t *__restrict__ Asl,
-                                                                    uint32_t *__restrict__ info_hat, long long B, int K, int Kw,
-                                                                    const uint32_t *__restrict__ truth, int nbits,
-                                                                    unsigned long long *__restrict__ counters)
+struct PolarStaticShape {
+    static constexpr int NLOG = POLAR_STATIC_NLOG;
+    static constexpr int PAIRS = 1 << (NLOG - 5);
+    static constexpr int KEEP = POLAR_STATIC_KEEP < PAIRS ? POLAR_STATIC_KEEP : PAIRS;
+    static constexpr int KL = (PAIRS - KEEP) < POLAR_STATIC_KEEP_LDS ? (PAIRS - KEEP) : POLAR_STATIC_KEEP_LDS;
+    static constexpr int KEPT_WORDS = 2 * KL * 64;  // per wavefront
+};
+// Workgroups of SC_STATIC_WAVES wavefronts share the gather table; everything else is per wavefront (the wavefronts
+// of a workgroup never wait for each other after the table is loaded).
+extern "C" __global__ void __launch_bounds__(64 * SC_STATIC_WAVES, POLAR_STATIC_WAVES) sc_static_kernel(
+    const float *__restrict__ llr, const uint16_t *__restrict__ Asl, uint32_t *__restrict__ info_hat, long long B, int K, int Kw,
+    const uint32_t *__restrict__ truth, int nbits, unsigned long long *__restrict__ counters)
 {
-    __shared__ __attribute__((aligned(32))) uint32_t stage[SC_STAGE_WORDS];
     constexpr int NLOG = POLAR_STATIC_NLOG;
     constexpr int N = 1 << NLOG;
-    __shared__ uint32_t asl_s[GatherShape<NLOG>::WORDS];
-    for (int k = threadIdx.x; k < GatherShape<NLOG>::WORDS; k += 64) asl_s[k] = Asl[k];
-    wave_sync();
-    const int lane = threadIdx.x;
+    constexpr int KEPT = PolarStaticShape::KEPT_WORDS;
+    __shared__ __attribute__((aligned(32))) uint32_t stage_s[SC_STATIC_WAVES * SC_STAGE_WORDS];
+    __shared__ uint16_t asl_s[GatherShape<NLOG>::WORDS];
+    __shared__ float kept_s[SC_STATIC_WAVES * (KEPT > 0 ? KEPT : 1)];
+    for (int k = threadIdx.x; k < GatherShape<NLOG>::WORDS; k += 64 * SC_STATIC_WAVES) asl_s[k] = Asl[k];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     const int grp = lane >> 4;
     const int sub = lane & 15;
-    StaticDec<NLOG, POLAR_STATIC_KEEP> d;
+    uint32_t *stage = stage_s + wave * SC_STAGE_WORDS;
     ErrAcc acc;
     RowConst rc;
 #pragma unroll
@@ -382,12 +408,14 @@ extern "C" __global__ void __launch_bounds__(64, POLAR_STATIC_WAVES) sc_static_k
         rc.lowmask[i] = rc.up[i] ? 0u : 0xFFFFFFFFu;
         rc.low31[i] = rc.up[i] ? 0u : 0x80000000u;
     }
-    for (long long f0 = (long long)blockIdx.x * 4; f0 < B; f0 += (long long)gridDim.x * 4) {
+    StaticDec<NLOG, PolarStaticShape::KEEP, PolarStaticShape::KL> d;
+    d.kept = kept_s + wave * KEPT + lane;
+    const long long stride = (long long)gridDim.x * (4 * SC_STATIC_WAVES);
+    for (long long f0 = ((long long)blockIdx.x * SC_STATIC_WAVES + wave) * 4; f0 < B; f0 += stride) {
         const long long f = f0 + grp;
         const bool active = f < B;
         const long long fc = active ? f : B - 1;
-        const float *chan_lane = llr + fc * N + sub;
-        decode_static<PolarStaticProfile, NLOG, 0, 0, NLOG, POLAR_STATIC_KEEP>(d, chan_lane, rc);
+        decode_static<PolarStaticProfile, NLOG, 0, 0>(d, llr + fc * N + sub, rc);
         sc_reg_epilogue<NLOG>(d.root, stage, asl_s, info_hat, fc, active, lane, K, Kw, truth, nbits, &acc);
     }
     if (truth) err_acc_flush(acc, counters);

@@ -201,13 +201,15 @@ extern "C" int polar_code_create(polar_ctx *ctx, int N, const uint8_t *mask, pol
     // Gather table of the register SC kernels' output stage: entry [i * TW + w] locates information bit 32 w + i
     // in the frame's staged u_hat (element k in lane k mod 16, bit k / 16 of the lane's 64-bit slice, stored as
     // words 2 lane, 2 lane + 1): (word << 5) | bit.  TW = words per row; unused entries stay zero.
-    std::vector<uint32_t> Asl;
+    std::vector<uint32_t> Asl;  // 16-bit entries, two per word
     if (N <= 1024) {
         const int TW = std::max(N / 32, 16);
-        Asl.assign((size_t)32 * TW, 0u);
+        Asl.assign((size_t)32 * TW / 2, 0u);
         for (size_t k = 0; k < A.size(); k++) {
             const uint32_t pos = A[k], lane = pos & 15u, j = pos >> 4;
-            Asl[(k & 31) * TW + (k >> 5)] = ((2u * lane + (j >> 5)) << 5) | (j & 31u);
+            const uint32_t e = ((2u * lane + (j >> 5)) << 5) | (j & 31u);
+            const size_t at = (k & 31) * TW + (k >> 5);
+            Asl[at >> 1] |= e << (16 * (at & 1));
         }
     }
     std::vector<uint32_t> Asl8;

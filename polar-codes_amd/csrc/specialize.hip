@@ -16,8 +16,9 @@ static int compile_static(const uint8_t *mask, int N, const char *arch, std::vec
     int n = 0;
     while ((1 << n) < N) n++;
     std::string src;
-    // experiment knobs: channel pairs kept in registers per lane, and the occupancy the compiler aims for
+    // experiment knobs: channel pairs kept in registers / in LDS per lane, and the occupancy the compiler aims for
     if (const char *e = getenv("POLAR_STATIC_KEEP")) src += "#define POLAR_STATIC_KEEP " + std::to_string(atoi(e)) + "\n";
+    if (const char *e = getenv("POLAR_STATIC_KEEP_LDS")) src += "#define POLAR_STATIC_KEEP_LDS " + std::to_string(atoi(e)) + "\n";
     if (const char *e = getenv("POLAR_STATIC_WAVES")) src += "#define POLAR_STATIC_WAVES " + std::to_string(atoi(e)) + "\n";
     src += "#define POLAR_STATIC_NLOG " + std::to_string(n) + "\n#define POLAR_STATIC_WORDS ";
     for (int w = 0; w < (N + 31) / 32; w++) {
@@ -106,10 +107,12 @@ int launch_sc_static(polar_code *c, const void *llr, uint32_t *info_hat, int64_t
 {
     if (B == 0) return POLAR_OK;
     polar_ctx *ctx = c->ctx;
+    constexpr int WAVES = 4;  // wavefronts per workgroup (SC_STATIC_WAVES in the kernel source)
     int occ = 0;
-    HIP_TRY(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, c->static_fn, 64, 0));
+    HIP_TRY(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, c->static_fn, 64 * WAVES, 0));
     if (occ < 1) occ = 1;
-    const int64_t need = (B + 3) / 4;
+    const int64_t per_block = 4 * WAVES;
+    const int64_t need = (B + per_block - 1) / per_block;
     const int64_t grid = std::min<int64_t>(need, (int64_t)ctx->num_cus * occ * 8);
     const void *a_llr = llr;
     const void *a_asl = c->d_Asl;
@@ -120,12 +123,14 @@ int launch_sc_static(polar_code *c, const void *llr, uint32_t *info_hat, int64_t
     void *a_cnt = c->count_dev;
     void *args[] = {&a_llr, &a_asl, &a_out, &a_B, &a_K, &a_Kw, &a_truth, &a_nbits, &a_cnt};
     LaunchTimer tm(ctx);
-    HIP_TRY(hipModuleLaunchKernel(c->static_fn, (unsigned)grid, 1, 1, 64, 1, 1, 0, ctx->stream, args, nullptr));
+    HIP_TRY(hipModuleLaunchKernel(c->static_fn, (unsigned)grid, 1, 1, 64 * WAVES, 1, 1, 0, ctx->stream, args, nullptr));
     float ms = tm.stop();
     snprintf(c->last.kernel, sizeof(c->last.kernel), "sc_static_kernel<%d>", c->n);
     c->last.lanes_per_frame = 16;
-    c->last.lds_bytes_per_block = 4 * (256 + 32 * std::max(c->N / 32, 16));
-    c->last.block_threads = 64;
+    int lds_bytes = 0;
+    (void)hipFuncGetAttribute(&lds_bytes, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, c->static_fn);
+    c->last.lds_bytes_per_block = lds_bytes;
+    c->last.block_threads = 64 * WAVES;
     c->last.grid_blocks = (int)grid;
     c->last.last_ms = ms;
     return POLAR_OK;
