@@ -150,14 +150,19 @@ template <int NLOG_, int KEEP = 0, int KL = 0> struct StaticDec {
                 b = R[3 * c + j];
             }
         };
+        const uint32_t sg = vgpr_const(0x80000000u);
         if constexpr (IS_G && c >= 2) {
-            // two elements per addition (packed fp32 add)
+            // two elements per addition (packed fp32 add); the sum of element j reaches bit 31 by doubling
+            uint32_t t = X[LEV - 5][0];
 #pragma unroll
             for (int j = 0; j < c; j += 2) {
                 float a0, b0, a1, b1;
                 fetch(j, a0, b0);
                 fetch(j + 1, a1, b1);
-                const uint32_t s0 = (X[LEV - 5][0] << j) & 0x80000000u, s1 = (X[LEV - 5][0] << (j + 1)) & 0x80000000u;
+                const uint32_t s0 = t & sg;
+                t = twice(t);
+                const uint32_t s1 = t & sg;
+                t = twice(t);
                 const f32x2 r = f32x2{b0, b1} + f32x2{__uint_as_float(__float_as_uint(a0) ^ s0), __uint_as_float(__float_as_uint(a1) ^ s1)};
                 R[c + j] = r.x;
                 R[c + j + 1] = r.y;
@@ -168,7 +173,7 @@ template <int NLOG_, int KEEP = 0, int KL = 0> struct StaticDec {
                 float a, b;
                 fetch(j, a, b);
                 if constexpr (IS_G) {
-                    const uint32_t sgn = (X[LEV - 5][0] << j) & 0x80000000u;
+                    const uint32_t sgn = X[LEV - 5][0] & sg;  // c == 1
                     R[c + j] = b + __uint_as_float(__float_as_uint(a) ^ sgn);
                 } else {
                     R[c + j] = f_fast(a, b);
@@ -181,8 +186,9 @@ template <int NLOG_, int KEEP = 0, int KL = 0> struct StaticDec {
         constexpr int c = 1 << (LEV - 5);  // elements per child
         uint32_t xl = X[LEV - 5][0], xr = X[LEV - 5][1];
         if constexpr (LEV == 5) {  // 16-leaf nodes deliver bit 31 only
-            xl &= 0x80000000u;
-            xr &= 0x80000000u;
+            const uint32_t sg = vgpr_const(0x80000000u);
+            xl &= sg;
+            xr &= sg;
         }
         if constexpr (LEV == NLOG) {
             if constexpr (c == 32) root = (ps_t)__builtin_bitreverse32(xl ^ xr) | ((ps_t)__builtin_bitreverse32(xr) << 32);
@@ -305,14 +311,14 @@ __device__ __forceinline__ void sc_reg_epilogue(ps_t root, uint32_t *stage, cons
     if (info_hat || truth) {
         constexpr int TW = GatherShape<NLOG>::TW;
         const unsigned char *base = reinterpret_cast<const unsigned char *>(stage);
-        const uint32_t goff = (uint32_t)grp << 2;
+        const uint32_t goff = (uint32_t)grp << 2, wordmask = vgpr_const(~31u);
         auto gather = [&](int w) {
             const uint16_t *t = Asl + w;
             uint32_t acc = 0;
 #pragma unroll
             for (int i = 0; i < 32; i++) {
                 const uint32_t e = t[i * TW];  // (staged word << 5) | bit
-                const uint32_t word = *reinterpret_cast<const uint32_t *>(base + ((e & ~31u) | goff));
+                const uint32_t word = *reinterpret_cast<const uint32_t *>(base + and_or(e, wordmask, goff));
                 acc = __builtin_amdgcn_alignbit(word >> (e & 31u), acc, 1);  // bit i of acc after 32 steps
             }
             const int valid = K - 32 * w;  // unused table entries point at bit 0 of the slice

@@ -59,11 +59,29 @@ __device__ __forceinline__ float minabs(float a, float b)
     return m;
 #endif
 }
+// Issue cost on gfx950 (scripts/micro/valutest.hip): add / sub / mul / fma, and / or / xor, right shifts and v_bitop3
+// with three VGPR sources run at full rate; anything with a scalar-register source, left shifts, min / max, the other
+// three-operand integer instructions (v_and_or, v_lshl_or, v_alignbit, v_bfe ...), comparisons and every DPP form at
+// half of it.  Hence: constants that feed bit logic sit in VGPRs, (a & b) | c is spelt as v_bitop3, and a left shift
+// by one is an addition.
+__device__ __forceinline__ uint32_t vgpr_const(uint32_t c)
+{
+    uint32_t m;
+    asm("v_mov_b32 %0, %1" : "=v"(m) : "s"(c));  // not volatile: one copy per kernel is enough
+    return m;
+}
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xEA); }
+__device__ __forceinline__ uint32_t twice(uint32_t x)
+{
+    uint32_t r;
+    asm("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(x));  // x << 1 at the full rate (the compiler would turn x + x into a shift)
+    return r;
+}
 // sign(a) sign(b) min(|a|,|b|) in three vector instructions
 __device__ __forceinline__ float f_fast(float a, float b)
 {
     const uint32_t s = __float_as_uint(a) ^ __float_as_uint(b);
-    return __uint_as_float((s & 0x80000000u) | __float_as_uint(minabs(a, b)));
+    return __uint_as_float(and_or(s, vgpr_const(0x80000000u), __float_as_uint(minabs(a, b))));
 }
 __device__ __forceinline__ double f_fast(double a, double b) { return f_minsum(a, b); }
 // b + (bit ? -a : a) with the bit as an integer 0/1

@@ -1,62 +1,112 @@
-// Vector-ALU issue rate of one CU as a function of the wavefronts per SIMD and of how many independent instruction
-// chains each wavefront carries.  Prints wave-instructions per cycle per SIMD (clock from wall_clock64 is not the
-// shader clock, so the rate is also given per nanosecond).
+// Issue rate of single vector instructions on one SIMD: CHAINS independent dependency chains per wavefront, 16
+// instructions per chain and loop trip, written as inline assembly so that the compiler neither fuses nor packs them.
+// Prints wave-instructions per nanosecond per SIMD for 4 and 8 wavefronts per SIMD.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
-template <int CHAINS, int KIND> __global__ void __launch_bounds__(64) valutest(float *out, int iters)
+#define OP1(txt) asm volatile(txt : "+v"(a[c]) : "v"(b[c]), "v"(d[c]), "s"(k) : "vcc")
+template <int CHAINS, int KIND> __global__ void __launch_bounds__(64) valutest(float *out, int iters, uint32_t k)
 {
-    float a[CHAINS];
-    uint32_t u[CHAINS];
+    uint32_t a[CHAINS], b[CHAINS], d[CHAINS];
+    uint64_t w[CHAINS];
 #pragma unroll
     for (int c = 0; c < CHAINS; c++) {
-        a[c] = (float)threadIdx.x * 0.001f + (float)c;
-        u[c] = threadIdx.x * 2654435761u + c;
+        a[c] = threadIdx.x * 2654435761u + c;
+        b[c] = threadIdx.x * 40503u + 7 * c;
+        d[c] = threadIdx.x + 13 * c;
+        w[c] = ((uint64_t)a[c] << 32) | b[c];
     }
     for (int i = 0; i < iters; i++) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
 #pragma unroll
             for (int c = 0; c < CHAINS; c++) {
-                if (KIND == 0) a[c] = __builtin_fmaf(a[c], 1.0001f, 0.5f);                     // v_fma_f32
-                else if (KIND == 1) u[c] = (u[c] ^ 0x9E3779B9u) + (u[c] >> 3);                    // xor / shift-add: 2 ops
-                else a[c] = __builtin_fminf(__builtin_fabsf(a[c]), 3.0f) + 1.0f;                   // min + add: 2 ops
+                if (KIND == 0) asm volatile("v_lshlrev_b32 %0, %1, %0" : "+v"(a[c]) : "v"(b[c]), "v"(d[c]), "s"(k) : "vcc");
+                else if (KIND == 1) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(a[c]) : "v"(b[c]), "v"(d[c]), "s"(k) : "vcc");
+                else if (KIND == 2) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(a[c]) : "v"(b[c]), "v"(d[c]), "s"(k) : "vcc");
+                else if (KIND == 3) asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(a[c]) : "v"(b[c]), "v"(d[c]), "s"(k) : "vcc");
+                else if (KIND == 4) asm volatile("v_lshrrev_b32 %0, %1, %0" : "+v"(a[c]) : "v"(b[c]), "v"(d[c]), "s"(k) : "vcc");
+                else if (KIND == 5) asm volatile("v_ashrrev_i32 %0, 3, %0" : "+v"(a[c]) : "v"(b[c]), "v"(d[c]), "s"(k) : "vcc");
+                else if (KIND == 6) asm volatile("v_add_u32 %0, %0, %0" : "+v"(a[c]) : "v"(b[c]), "v"(d[c]), "s"(k) : "vcc");
+                else if (KIND == 7) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a[c]) : "v"(b[c]), "v"(d[c]), "s"(k) : "vcc");
+                else if (KIND == 8) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[c]) : "v"(b[c]), "v"(d[c]), "s"(k) : "vcc");
+                else if (KIND == 9) asm volatile("v_bfrev_b32 %0, %0" : "+v"(a[c]) : "v"(b[c]), "v"(d[c]), "s"(k) : "vcc");
+                else if (KIND == 10) asm volatile("v_and_b32 %0, 0x7fffffff, %0" : "+v"(a[c]) : "v"(b[c]), "v"(d[c]), "s"(k) : "vcc");
+                else if (KIND == 11) asm volatile("v_and_b32 %0, %3, %0" : "+v"(a[c]) : "v"(b[c]), "v"(d[c]), "s"(k) : "vcc");
+                else if (KIND == 12) asm volatile("v_fma_f32 %0, %0, %3, %1" : "+v"(a[c]) : "v"(b[c]), "v"(d[c]), "s"(k) : "vcc");
+                else if (KIND == 13) asm volatile("v_fma_f32 %0, %0, 1.0, %1" : "+v"(a[c]) : "v"(b[c]), "v"(d[c]), "s"(k) : "vcc");
+                else if (KIND == 14) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(a[c]) : "v"(b[c]), "v"(d[c]), "s"(k) : "vcc");
+                else if (KIND == 15) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[c]) : "v"(b[c]), "v"(d[c]), "s"(k) : "vcc");
+                else if (KIND == 16) asm volatile("v_xor_b32 %0, %0, %1\n v_add_f32 %0, %0, %2" : "+v"(a[c]) : "v"(b[c]), "v"(d[c]), "s"(k) : "vcc");
+                else if (KIND == 17) asm volatile("v_cmp_gt_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[c]) : "v"(b[c]), "v"(d[c]), "s"(k) : "vcc");
+                else if (KIND == 18) asm volatile("v_cmp_gt_f32 s[20:21], %0, %1" : "+v"(a[c]) : "v"(b[c]), "v"(d[c]), "s"(k) : "vcc", "s20", "s21");
+                else if (KIND == 19) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(a[c]) : "v"(b[c]), "v"(d[c]), "s"(k) : "vcc");
+                else if (KIND == 20) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[c]) : "v"(b[c]), "v"(d[c]), "s"(k) : "vcc");
+                else if (KIND == 21) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(w[c]) : "v"(b[c]), "v"(d[c]) : "vcc");
+                else if (KIND == 22) asm volatile("v_exp_f32 %0, %0" : "+v"(a[c]) : "v"(b[c]), "v"(d[c]), "s"(k) : "vcc");
+                else if (KIND == 23) asm volatile("v_sin_f32 %0, %0" : "+v"(a[c]) : "v"(b[c]), "v"(d[c]), "s"(k) : "vcc");
+                else if (KIND == 24) asm volatile("v_log_f32 %0, %0" : "+v"(a[c]) : "v"(b[c]), "v"(d[c]), "s"(k) : "vcc");
+                else if (KIND == 25) asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[c]) : "v"(b[c]), "v"(d[c]), "s"(k) : "vcc");
             }
         }
     }
-    float s = 0.f;
+    uint32_t s = 0;
 #pragma unroll
-    for (int c = 0; c < CHAINS; c++) s += a[c] + (float)u[c];
-    if (s == 12345.678f) out[0] = s;
+    for (int c = 0; c < CHAINS; c++) s += a[c] + (uint32_t)w[c];
+    if (s == 0x12345678u) out[0] = (float)s;
 }
-template <int CHAINS, int KIND> static void run(int waves_per_simd, int ops_per_step)
+template <int CHAINS, int KIND> static void run(const char *name)
 {
     float *out;
-    hipMalloc(&out, 4);
+    (void)hipMalloc(&out, 4);
     hipDeviceProp_t p;
-    hipGetDeviceProperties(&p, 0);
-    const int cus = p.multiProcessorCount, iters = 4096;
+    (void)hipGetDeviceProperties(&p, 0);
+    const int cus = p.multiProcessorCount, iters = 8192;
     hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
-    const int grid = cus * 4 * waves_per_simd;
-    hipLaunchKernelGGL((valutest<CHAINS, KIND>), dim3(grid), dim3(64), 0, 0, out, 16);
-    hipEventRecord(e0);
-    hipLaunchKernelGGL((valutest<CHAINS, KIND>), dim3(grid), dim3(64), 0, 0, out, iters);
-    hipEventRecord(e1);
-    hipEventSynchronize(e1);
-    float ms;
-    hipEventElapsedTime(&ms, e0, e1);
-    const double instr_per_simd = (double)waves_per_simd * iters * 16 * CHAINS * ops_per_step;
-    printf("kind %d chains %d waves/SIMD %d: %.3f ms, %.3f wave-instructions per ns per SIMD (at 2.4 GHz: %.3f per cycle)\n", KIND, CHAINS,
-           waves_per_simd, ms, instr_per_simd / (ms * 1e6), instr_per_simd / (ms * 1e6) / 2.4);
-    hipFree(out);
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    printf("%-44s chains %d:", name, CHAINS);
+    for (int w : {4, 8}) {
+        const int grid = cus * 4 * w;
+        hipLaunchKernelGGL((valutest<CHAINS, KIND>), dim3(grid), dim3(64), 0, 0, out, 16, 0x80000000u);
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL((valutest<CHAINS, KIND>), dim3(grid), dim3(64), 0, 0, out, iters, 0x80000000u);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        printf("  %d waves/SIMD %.3f/ns", w, (double)w * iters * 16 * CHAINS / (ms * 1e6));
+    }
+    printf("\n");
+    (void)hipFree(out);
 }
 int main()
 {
-    for (int w : {1, 2, 4, 8}) run<1, 0>(w, 1);
-    for (int w : {1, 2, 4, 8}) run<4, 0>(w, 1);
-    for (int w : {1, 2, 4, 8}) run<4, 1>(w, 2);
-    for (int w : {1, 2, 4, 8}) run<4, 2>(w, 2);
+    run<4, 0>("v_lshlrev_b32 v,v");
+    run<4, 1>("v_lshlrev_b32 3,v");
+    run<4, 2>("v_lshlrev_b32 1,v");
+    run<4, 3>("v_lshrrev_b32 3,v");
+    run<4, 4>("v_lshrrev_b32 v,v");
+    run<4, 5>("v_ashrrev_i32 3,v");
+    run<4, 6>("v_add_u32 v,v same reg");
+    run<4, 7>("v_mul_u32_u24");
+    run<4, 8>("v_min_u32");
+    run<4, 9>("v_bfrev_b32");
+    run<4, 10>("v_and_b32 literal");
+    run<4, 11>("v_and_b32 s,v");
+    run<4, 12>("v_fma_f32 v,s,v");
+    run<4, 13>("v_fma_f32 v,1.0,v");
+    run<4, 14>("v_add_f32 1.0,v");
+    run<4, 15>("v_sub_f32");
+    run<4, 16>("xor + add (2 instr)");
+    run<4, 17>("cmp + cndmask (2 instr)");
+    run<4, 18>("v_cmp_gt_f32 -> sgpr pair");
+    run<4, 19>("v_cvt_f32_u32");
+    run<4, 20>("v_mul_lo_u32");
+    run<4, 21>("v_mad_u64_u32 (64-bit acc)");
+    run<4, 22>("v_exp_f32");
+    run<4, 23>("v_sin_f32");
+    run<4, 24>("v_log_f32");
+    run<4, 25>("v_sqrt_f32");
     return 0;
 }
