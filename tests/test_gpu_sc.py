@@ -208,7 +208,7 @@ def test_sc_every_compiled_16_leaf_profile(monkeypatch):
                 assert np.array_equal(info, ref), fast
 
 
-@pytest.mark.parametrize("N,K", [(32, 16), (64, 20), (128, 64), (256, 200), (512, 100), (1024, 512)])
+@pytest.mark.parametrize("N,K", [(32, 16), (64, 20), (128, 64), (256, 200), (512, 100), (1024, 512), (1024, 800), (1024, 1023)])
 def test_sc_specialised_kernel_equals_generic(monkeypatch, N, K):
     """The decoder compiled at run time for one rate profile against the generic register kernel and the oracle."""
     rs = np.random.RandomState(N + K)
@@ -233,6 +233,46 @@ def test_sc_specialised_kernel_equals_generic(monkeypatch, N, K):
         plain = _native.Code(_native.default_ctx(), mask)
         n0 = n0_of(2.0, Kc / N)
         assert code.mc_run(_native.DEC_SC, 1, np.float32, n0, 5, 0, 20000).tolist() == plain.mc_run(_native.DEC_SC, 1, np.float32, n0, 5, 0, 20000).tolist()
+
+
+@pytest.mark.parametrize("N,K", [(64, 32), (1024, 512), (1024, 700)])
+def test_sc_signed_zeros_and_extremes(monkeypatch, N, K):
+    """Decisions are `LLR < 0`: +0 and -0 both decide 0, also where they only arise inside the tree (f of a zero and a
+    negative value is -0; equal magnitudes cancel to +0).  Zeros, signed zeros, repeated magnitudes, denormals and huge
+    values: the every-leaf schedule equals the oracle on all of them; the schedule with short-cuts takes the signs of
+    an all-information subtree's LLRs, which is the leaf-by-leaf result unless one of those LLRs is exactly zero, so
+    it is held to the oracle on the all-zero rows and otherwise to itself: generic register kernel, specialised
+    kernel and LDS-staged kernel must agree bit for bit."""
+    rs = np.random.RandomState(N * 3 + K)
+    mask = pcf.degaBuild(N, K, 2.0)
+    code = _native.Code(_native.default_ctx(), mask)
+    B = 64
+    llr = np.zeros((B, N), dtype=np.float32)
+    llr[1] = -0.0
+    llr[2] = np.where(rs.rand(N) < 0.5, 0.0, -0.0)
+    llr[3] = rs.choice([-1.0, 1.0], size=N)                         # every g cancels or doubles
+    llr[4] = rs.choice([-2.0, -1.0, -0.0, 0.0, 1.0, 2.0], size=N)
+    llr[5] = rs.choice([-1e-42, 1e-42, 0.0, -0.0], size=N)          # denormals
+    llr[6] = rs.choice([-3e37, 3e37, 1.0, -1.0], size=N)            # sums that overflow to infinity
+    for b in range(7, B):
+        v = rs.choice([-2.0, -1.0, -0.5, -0.0, 0.0, 0.5, 1.0, 2.0], size=N) * rs.choice([1.0, 1.0, 3.0], size=N)
+        llr[b] = np.where(rs.rand(N) < 0.3, 0.0, v)
+    ref = np.stack([oracle.extract(oracle.sc_decode(llr[b], mask), mask) for b in range(B)])
+    plain, _, _ = code.sc_decode(llr, fast=False)
+    assert code.last_launch()["kernel"].startswith("sc_reg_kernel")
+    assert np.array_equal(plain, ref)
+    gen, _, _ = code.sc_decode(llr, fast=True)
+    assert code.last_launch()["kernel"].startswith("sc_reg_kernel")
+    assert np.array_equal(gen[:3], ref[:3])
+    monkeypatch.setenv("POLAR_SC_KERNEL", "lds")
+    lds, _, _ = code.sc_decode(llr, fast=True)
+    assert code.last_launch()["kernel"].startswith("sc_decode_kernel")
+    monkeypatch.delenv("POLAR_SC_KERNEL")
+    assert np.array_equal(lds, gen)
+    code.specialize()
+    spec, _, _ = code.sc_decode(llr, fast=True)
+    assert code.last_launch()["kernel"].startswith("sc_static_kernel")
+    assert np.array_equal(spec, gen)
 
 
 def n0_of(snr_db, rate):
