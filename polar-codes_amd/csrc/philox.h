@@ -7,16 +7,25 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+__device__ __forceinline__ uint32_t philox_vgpr(uint32_t c)
+{
+    uint32_t m;
+    asm("v_mov_b32 %0, %1" : "=v"(m) : "s"(c));  // not volatile: one copy per kernel
+    return m;
+}
+// On gfx950 a vector instruction with a scalar-register source issues at half rate, so the multipliers and the key
+// schedule sit in vector registers, and each of the two three-way exclusive-ors of a round is one v_bitop3.
 __device__ __forceinline__ void philox4x32_10(uint64_t frame, uint32_t block, uint32_t stream, uint64_t seed, uint32_t out[4])
 {
     uint32_t c0 = (uint32_t)frame, c1 = (uint32_t)(frame >> 32), c2 = block, c3 = stream;
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    uint32_t k0 = philox_vgpr((uint32_t)seed), k1 = philox_vgpr((uint32_t)(seed >> 32));
+    const uint32_t M0 = philox_vgpr(0xD2511F53u), M1 = philox_vgpr(0xCD9E8D57u);
 #pragma unroll
     for (int r = 0; r < 10; r++) {
         // one 32 x 32 -> 64 multiply-add per product (v_mad_u64_u32) instead of a low and a high multiply
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96), n2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
         c0 = n0;
         c1 = lo1;
         c2 = n2;

@@ -11,7 +11,7 @@ import csv,glob,collections
 for d in sorted(glob.glob('$R/gpurun_out/pmc3_*/*/*_counter_collection.csv')):
     agg=collections.defaultdict(list)
     for r in csv.DictReader(open(d)):
-        if any(k in r['Kernel_Name'] for k in ('sc_reg_kernel','sc_static_kernel')):
+        if any(k in r['Kernel_Name'] for k in '${POLAR_PMC_KERNELS:-sc_reg_kernel,sc_static_kernel}'.split(',')):
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
     for k,v in agg.items():
         print(k, 'n=%d'%len(v), 'avg=%.4g'%(sum(v)/len(v)), 'per wave pass (1M)=%.1f'%(sum(v)/len(v)/1e6))
