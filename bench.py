@@ -367,13 +367,21 @@ def main():
         except _native.PolarError as e:
             extras["ca_scl8_1024_512_crc24"] = {"error": str(e)}
         ctx.enable_timing(False)
-        # fused Monte-Carlo pipeline (generate + decode + count), nothing resident beforehand
-        code.mc_run(_native.DEC_SC, 1, np.float32, ch.noisePower, seed, 0, (1 << 20) + 4096)  # sizes both buffers of the pipeline
+        # the Monte-Carlo loop (draw, encode, channel, decode, count), nothing resident beforehand: as one kernel without an
+        # LLR buffer (what polar_mc_run does for a specialised code), and as generator -> buffer -> decoder
         nmc = 1 << 24
-        t0 = time.perf_counter()
-        mc = code.mc_run(_native.DEC_SC, 1, np.float32, ch.noisePower, seed, 0, nmc)
-        mdt = time.perf_counter() - t0
-        extras["mc_pipeline_sc"] = {"frames_per_s": nmc / mdt, "info_mbps": nmc * K / mdt / 1e6, "frames": nmc, "fer": int(mc[1]) / int(mc[0])}
+        for name, staged in (("mc_fused_sc", False), ("mc_pipeline_sc", True)):
+            if staged:
+                os.environ["POLAR_MC_KERNEL"] = "staged"
+            try:
+                code.mc_run(_native.DEC_SC, 1, np.float32, ch.noisePower, seed, 0, (1 << 20) + 4096)  # warm-up, sizes the buffers
+                t0 = time.perf_counter()
+                mc = code.mc_run(_native.DEC_SC, 1, np.float32, ch.noisePower, seed, 0, nmc)
+                mdt = time.perf_counter() - t0
+                extras[name] = {"frames_per_s": nmc / mdt, "info_mbps": nmc * K / mdt / 1e6, "frames": nmc, "fer": int(mc[1]) / int(mc[0]),
+                                "counters": [int(v) for v in mc], "kernel": code.last_launch()["kernel"]}
+            finally:
+                os.environ.pop("POLAR_MC_KERNEL", None)
         out["extras"] = extras
 
     if rank == 0 and world == 1 and not a.no_cpu:

@@ -11,7 +11,8 @@
 // after each f/g step the values are replicated with half the period, every lane runs the same
 // instruction stream and keeps the partial-sum bit of "its" element.
 // No LDS is used on the decoding path; the channel LLRs are read from global memory by the two
-// top-level operations, and LDS only stages 8 bytes per lane for the final gather of the info bits.
+// top-level operations.  LDS holds the output stage: 8 bytes of u_hat per lane and the table (two bytes per
+// information bit) that says where each information bit sits in them.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>

@@ -9,9 +9,22 @@
 // (unrolled decoders in the sense of Giard et al.).  Arithmetic and results are those of sc_reg_kernel.
 #pragma once
 #include "reg_common.h"
+#include "philox.h"
 
 typedef uint64_t ps_t;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int V> struct IntTag {
+    static constexpr int value = V;
+};
+// f(IntTag<I>{}) for I = BEGIN .. END-1, unrolled at compile time
+template <int BEGIN, int END, typename F> __device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (BEGIN < END) {
+        f(IntTag<BEGIN>{});
+        static_for<BEGIN + 1, END>(f);
+    }
+}
 
 template <typename T, int NLOG, int KEEP = 0> struct RegDec {
     static constexpr int S = 1 << (NLOG - 4);  // slice length per lane
@@ -107,7 +120,16 @@ template <int NW> struct StaticProfile {
 // known when the kernel is compiled.
 // Of the lane's 2^(NLOG-5) channel pairs the first KEEP stay in registers between the top-level f and g, the next KL in
 // LDS (kept[k * 64], k = 2 pair, 2 pair + 1: the wavefront's region, one column per lane); the rest is read again.
-template <int NLOG_, int KEEP = 0, int KL = 0> struct StaticDec {
+// With GEN the channel LLRs are not read but made: the lane's slice of the transmitted codeword is in xlo / xhi, the
+// noise comes from the same Philox blocks as in gen_frames_kernel (block j of stream 1 gives the normals of code
+// positions 4j .. 4j+3), so the LLRs are bit for bit those the frame generator would have written.
+struct ChannelGen {
+    uint64_t frame, seed;
+    uint32_t xlo, xhi;
+    float sigma, gain;
+    int sub;
+};
+template <int NLOG_, int KEEP = 0, int KL = 0, bool GEN = false> struct StaticDec {
     static constexpr int NLOG = NLOG_;
     static constexpr int S = 1 << (NLOG - 4);
     float R[S];
@@ -115,11 +137,83 @@ template <int NLOG_, int KEEP = 0, int KL = 0> struct StaticDec {
     float *kept;
     uint32_t X[NLOG - 4][2];
     ps_t root;  // element j at bit j, as the output stage takes it
+    ChannelGen cg;
+
+    // LLRs of slice elements t = 4g .. 4g+3 (code positions 16 t + sub).  Lane 4a + b of a row makes Philox block
+    // 4 (4g + b) + a, the normals of positions 16 (4g + b) + 4a + i, i = 0..3: element b of what each lane b' of its
+    // quad made is what it needs, a 4 x 4 transpose inside the quad (two exchanges).
+    template <int G> __device__ __forceinline__ void llr_group(float out[4])
+    {
+        const int a = cg.sub >> 2, b = cg.sub & 3;
+        uint32_t r[4];
+        philox4x32_10(cg.frame, (uint32_t)(4 * (4 * G + b) + a), 1u, cg.seed, r);
+        float z[4];
+        box_muller<float>(r[0], r[1], z[0], z[1]);
+        box_muller<float>(r[2], r[3], z[2], z[3]);
+        const bool b0 = (b & 1) != 0, b1 = (b & 2) != 0;
+        {
+            const float r01 = dpp_mov<0xB1>(b0 ? z[0] : z[1]), r23 = dpp_mov<0xB1>(b0 ? z[2] : z[3]);  // partner b ^ 1
+            if (b0) {
+                z[0] = r01;
+                z[2] = r23;
+            } else {
+                z[1] = r01;
+                z[3] = r23;
+            }
+        }
+        {
+            const float r02 = dpp_mov<0x4E>(b1 ? z[0] : z[2]), r13 = dpp_mov<0x4E>(b1 ? z[1] : z[3]);  // partner b ^ 2
+            if (b1) {
+                z[0] = r02;
+                z[1] = r13;
+            } else {
+                z[2] = r02;
+                z[3] = r13;
+            }
+        }
+        const uint32_t xw = (4 * G < 32) ? cg.xlo : cg.xhi;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float s = ((xw >> ((4 * G + i) & 31)) & 1u) ? -1.0f : 1.0f;
+            out[i] = cg.gain * (s + cg.sigma * z[i]);
+        }
+    }
+    // top-level f with generated LLRs: pairs (t, t + 2^(NLOG-5)); every pair is kept (registers, then LDS) for the g
+    __device__ __forceinline__ void top_f_generate()
+    {
+        constexpr int c = 1 << (NLOG - 5);
+        static_assert(!GEN || (c >= 4 && KEEP + KL >= c), "generated channel: every pair must stay on chip");
+        auto group = [&](auto gtag) {
+            constexpr int G = decltype(gtag)::value;
+            float a4[4], b4[4];
+            llr_group<G>(a4);
+            llr_group<G + c / 4>(b4);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int j = 4 * G + i;
+                if (j < KEEP) {
+                    CA[j] = a4[i];
+                    CB[j] = b4[i];
+                } else {
+                    kept[(2 * (j - KEEP)) * 64] = a4[i];
+                    kept[(2 * (j - KEEP) + 1) * 64] = b4[i];
+                }
+                R[c + j] = f_fast(a4[i], b4[i]);
+            }
+            // one group at a time: letting the compiler overlap several of them costs more registers than there are
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        static_for<0, c / 4>(group);
+    }
 
     template <int LEV, bool IS_G> __device__ __forceinline__ void step(const float *chan_lane)
     {
         constexpr int c = 1 << (LEV - 5);
-        if constexpr (LEV == NLOG && IS_G) {
+        if constexpr (GEN && LEV == NLOG && !IS_G) {
+            top_f_generate();
+            return;
+        }
+        if constexpr (LEV == NLOG && IS_G && !GEN) {
             // the second read of the channel goes through an offset the compiler cannot see is zero: reusing
             // the values of the first read would keep the whole slice in registers, KEEP decides how much of it is
             uint32_t zero = 0;
@@ -244,6 +338,40 @@ __device__ __forceinline__ void decode_static(Dec &d, const float *chan_lane, co
 // Output stage shared with sc_reg_kernel: u_hat = x_hat F^{(x)n} on the sliced layout, staged in LDS, then lane `sub` of the frame's row assembles output words sub and sub + 16 on its own, one staged bit
 // per step, and the words leave as contiguous stores.  Asl is the gather table in LDS, [bit i][word w] with
 // GATHER_TW words per row: lanes of a row read neighbouring entries, the four rows the same ones.
+// x F^{(x)n} of a frame on the sliced layout (element k of the frame = bit k / 16 of lane k mod 16's 64-bit slice lo, hi;
+// hi is zero below N = 1024).  The transform is its own inverse: it takes x_hat to u_hat and u to x.
+template <int NLOG> __device__ __forceinline__ void slice_transform(uint32_t &lo, uint32_t &hi, int sub)
+{
+    // stages 4 .. NLOG-1 pair (j, j + 2^(s-4)) inside a lane
+    if constexpr (NLOG > 9) lo ^= hi;
+    if constexpr (NLOG > 4) lo ^= (lo >> 1) & 0x55555555u;
+    if constexpr (NLOG > 5) lo ^= (lo >> 2) & 0x33333333u;
+    if constexpr (NLOG > 6) lo ^= (lo >> 4) & 0x0F0F0F0Fu;
+    if constexpr (NLOG > 7) lo ^= (lo >> 8) & 0x00FF00FFu;
+    if constexpr (NLOG > 8) lo ^= (lo >> 16) & 0x0000FFFFu;
+    if constexpr (NLOG > 9) {
+        hi ^= (hi >> 1) & 0x55555555u;
+        hi ^= (hi >> 2) & 0x33333333u;
+        hi ^= (hi >> 4) & 0x0F0F0F0Fu;
+        hi ^= (hi >> 8) & 0x00FF00FFu;
+        hi ^= (hi >> 16) & 0x0000FFFFu;
+    }
+    // stages 0 .. 3 pair lanes (l, l + 2^s) of the row; the lower lane of a pair takes the upper one's word.  Inside
+    // a quad the word is masked to the upper lanes before the exchange; across quads the exchange itself is limited
+    // to the banks (quads) of the lower lanes.
+    const uint32_t odd1 = (sub & 1) ? 0xFFFFFFFFu : 0u, odd2 = (sub & 2) ? 0xFFFFFFFFu : 0u;
+    lo ^= dpp_mov_u32<0xB1>(lo & odd1);  // quad_perm:[1,0,3,2]
+    lo ^= dpp_mov_u32<0x4E>(lo & odd2);  // quad_perm:[2,3,0,1]
+    lo ^= dpp_banks_u32<0x104, 0x5>(lo);  // row_shl:4 into quads 0 and 2
+    lo ^= dpp_banks_u32<0x108, 0x3>(lo);  // row_shl:8 into quads 0 and 1
+    if constexpr (NLOG > 9) {
+        hi ^= dpp_mov_u32<0xB1>(hi & odd1);
+        hi ^= dpp_mov_u32<0x4E>(hi & odd2);
+        hi ^= dpp_banks_u32<0x104, 0x5>(hi);
+        hi ^= dpp_banks_u32<0x108, 0x3>(hi);
+    }
+}
+
 constexpr int SC_STAGE_WORDS = 256;  // per wavefront: 32 words per frame, one frame's word every 32 bytes
 constexpr int SC_STATIC_WAVES = 4;   // wavefronts per workgroup of the specialised kernel
 template <int NLOG> struct GatherShape {
@@ -265,50 +393,25 @@ __device__ __forceinline__ void err_acc_flush(const ErrAcc &a, unsigned long lon
 }
 
 // truth (packed [B x Kw], or NULL): the transmitted information words; their first nbits bits are compared with the
-// decoded ones and the result goes into acc.  info_hat may then be NULL (nothing is stored).
+// decoded ones and the result goes into acc.  info_hat may then be NULL (nothing is stored).  With truth_regs the
+// transmitted words are in tr_lo / tr_hi (lane sub of the frame's row: words sub and sub + 16).
 template <int NLOG>
 __device__ __forceinline__ void sc_reg_epilogue(ps_t root, uint32_t *stage, const uint16_t *Asl, uint32_t *__restrict__ info_hat,
                                                 int64_t fc, bool active, int lane, int K, int Kw,
-                                                const uint32_t *__restrict__ truth = nullptr, int nbits = 0, ErrAcc *acc = nullptr)
+                                                const uint32_t *__restrict__ truth = nullptr, int nbits = 0, ErrAcc *acc = nullptr,
+                                                bool truth_regs = false, uint32_t tr_lo = 0u, uint32_t tr_hi = 0u)
 {
     const int grp = lane >> 4, sub = lane & 15;
     uint32_t lo = (uint32_t)root, hi = (uint32_t)(root >> 32);
-    // stages 4 .. NLOG-1 pair (j, j + 2^(s-4)) inside a lane (hi is zero below N = 1024)
-    if constexpr (NLOG > 9) lo ^= hi;
-    if constexpr (NLOG > 4) lo ^= (lo >> 1) & 0x55555555u;
-    if constexpr (NLOG > 5) lo ^= (lo >> 2) & 0x33333333u;
-    if constexpr (NLOG > 6) lo ^= (lo >> 4) & 0x0F0F0F0Fu;
-    if constexpr (NLOG > 7) lo ^= (lo >> 8) & 0x00FF00FFu;
-    if constexpr (NLOG > 8) lo ^= (lo >> 16) & 0x0000FFFFu;
-    if constexpr (NLOG > 9) {
-        hi ^= (hi >> 1) & 0x55555555u;
-        hi ^= (hi >> 2) & 0x33333333u;
-        hi ^= (hi >> 4) & 0x0F0F0F0Fu;
-        hi ^= (hi >> 8) & 0x00FF00FFu;
-        hi ^= (hi >> 16) & 0x0000FFFFu;
-    }
-    // stages 0 .. 3 pair lanes (l, l + 2^s) of the row; the lower lane of a pair takes the upper one's word.  Inside
-    // a quad the word is masked to the upper lanes before the exchange; across quads the exchange itself is limited
-    // to the banks (quads) of the lower lanes.
+    slice_transform<NLOG>(lo, hi, sub);
     {
-        const uint32_t odd1 = (sub & 1) ? 0xFFFFFFFFu : 0u, odd2 = (sub & 2) ? 0xFFFFFFFFu : 0u;
-        lo ^= dpp_mov_u32<0xB1>(lo & odd1);  // quad_perm:[1,0,3,2]
-        lo ^= dpp_mov_u32<0x4E>(lo & odd2);  // quad_perm:[2,3,0,1]
-        lo ^= dpp_banks_u32<0x104, 0x5>(lo);  // row_shl:4 into quads 0 and 2
-        lo ^= dpp_banks_u32<0x108, 0x3>(lo);  // row_shl:8 into quads 0 and 1
-        if constexpr (NLOG > 9) {
-            hi ^= dpp_mov_u32<0xB1>(hi & odd1);
-            hi ^= dpp_mov_u32<0x4E>(hi & odd2);
-            hi ^= dpp_banks_u32<0x104, 0x5>(hi);
-            hi ^= dpp_banks_u32<0x108, 0x3>(hi);
-        }
         // staged word w (= 2 lane + half) of the frame in row g at byte 32 w + 4 g: a gather address is then the
         // table entry with its low five bits (the bit index) replaced
         stage[16 * sub + grp] = lo;
         if constexpr (NLOG > 9) stage[16 * sub + 8 + grp] = hi;
     }
     wave_sync();
-    if (info_hat || truth) {
+    if (info_hat || truth || truth_regs) {
         constexpr int TW = GatherShape<NLOG>::TW;
         const unsigned char *base = reinterpret_cast<const unsigned char *>(stage);
         const uint32_t goff = (uint32_t)grp << 2, wordmask = vgpr_const(~31u);
@@ -332,18 +435,23 @@ __device__ __forceinline__ void sc_reg_epilogue(ps_t root, uint32_t *stage, cons
             if (sub + 16 < Kw) dst[sub + 16] = w_hi;
             if (K == 0 && sub == 0) dst[0] = 0u;
         }
-        if (truth) {
-            const uint32_t *tw = truth + fc * Kw;
+        if (truth || truth_regs) {
+            // the transmitted words: lane `sub` holds words sub and sub + 16 itself, or they come from memory
+            if (!truth_regs) {
+                const uint32_t *tw = truth + fc * Kw;
+                tr_lo = sub < Kw ? tw[sub] : 0u;
+                tr_hi = sub + 16 < Kw ? tw[sub + 16] : 0u;
+            }
             uint32_t e = 0;
             if (sub < Kw) {
                 const int valid = nbits - 32 * sub;
                 const uint32_t m = valid >= 32 ? 0xFFFFFFFFu : (valid <= 0 ? 0u : ((1u << valid) - 1u));
-                e += __popc((w_lo ^ tw[sub]) & m);
+                e += __popc((w_lo ^ tr_lo) & m);
             }
             if (sub + 16 < Kw) {
                 const int valid = nbits - 32 * (sub + 16);
                 const uint32_t m = valid >= 32 ? 0xFFFFFFFFu : (valid <= 0 ? 0u : ((1u << valid) - 1u));
-                e += __popc((w_hi ^ tw[sub + 16]) & m);
+                e += __popc((w_hi ^ tr_hi) & m);
             }
             // sum over the 16 lanes of the frame's row
             e += dpp_mov_u32<0x128>(e);
@@ -426,4 +534,95 @@ extern "C" __global__ void __launch_bounds__(64 * SC_STATIC_WAVES, POLAR_STATIC_
     }
     if (truth) err_acc_flush(acc, counters);
 }
+
+#if POLAR_STATIC_NLOG >= 7  // a Philox block spans four slice elements: below N = 128 a lane has fewer pairs than that
+// Monte-Carlo frames without a channel buffer: information bits (Philox stream 0), rate profile and encoder, BPSK,
+// AWGN and LLRs (stream 1), the decoder above and the error count, all in registers and LDS of the wavefront that owns
+// the four frames.  Counters and every intermediate value are those of gen_frames_kernel followed by
+// sc_static_kernel: same Philox blocks, same arithmetic.  counters: frames, frame errors, bit errors.
+extern "C" __global__ void __launch_bounds__(64 * SC_STATIC_WAVES, POLAR_STATIC_WAVES) sc_static_mc_kernel(
+    const uint16_t *__restrict__ Asl, long long B, int K, int Kw, float sigma, float gain, unsigned long long seed,
+    unsigned long long frame0, unsigned long long *__restrict__ counters)
+{
+    constexpr int NLOG = POLAR_STATIC_NLOG;
+    constexpr int PAIRS = PolarStaticShape::PAIRS;
+    constexpr int KEEP = PolarStaticShape::KEEP;
+    constexpr int KL = PAIRS - KEEP;  // nothing can be read again: what is not in registers waits in LDS
+    constexpr int KEPT = 2 * KL * 64;
+    constexpr int TW = GatherShape<NLOG>::TW;
+    __shared__ __attribute__((aligned(32))) uint32_t stage_s[SC_STATIC_WAVES * SC_STAGE_WORDS];
+    __shared__ uint16_t asl_s[GatherShape<NLOG>::WORDS];
+    __shared__ float kept_s[SC_STATIC_WAVES * (KEPT > 0 ? KEPT : 1)];
+    for (int k = threadIdx.x; k < GatherShape<NLOG>::WORDS; k += 64 * SC_STATIC_WAVES) asl_s[k] = Asl[k];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane >> 4;
+    const int sub = lane & 15;
+    uint32_t *stage = stage_s + wave * SC_STAGE_WORDS;
+    ErrAcc acc;
+    RowConst rc;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        rc.up[i] = (sub & (8 >> i)) != 0;
+        rc.lowmask[i] = rc.up[i] ? 0u : 0xFFFFFFFFu;
+        rc.low31[i] = rc.up[i] ? 0u : 0x80000000u;
+    }
+    StaticDec<NLOG, KEEP, KL, true> d;
+    d.kept = kept_s + wave * KEPT + lane;
+    d.cg.seed = seed;
+    d.cg.sigma = sigma;
+    d.cg.gain = gain;
+    d.cg.sub = sub;
+    const long long stride = (long long)gridDim.x * (4 * SC_STATIC_WAVES);
+    for (long long f0 = ((long long)blockIdx.x * SC_STATIC_WAVES + wave) * 4; f0 < B; f0 += stride) {
+        const long long f = f0 + grp;
+        const bool active = f < B;
+        const long long fc = active ? f : B - 1;
+        d.cg.frame = frame0 + (unsigned long long)fc;
+        // information words sub and sub + 16 of the frame, as gen_frames_kernel draws them
+        uint32_t iw[2] = {0u, 0u};
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const int w = sub + 16 * s;
+            if (s == 0 || Kw > 16) {
+                uint32_t r[4];
+                philox4x32_10(d.cg.frame, (uint32_t)(w >> 2), 0u, seed, r);
+                uint32_t v = (w & 2) ? ((w & 1) ? r[3] : r[2]) : ((w & 1) ? r[1] : r[0]);
+                const int valid = K - 32 * w;
+                v = valid >= 32 ? v : (valid <= 0 ? 0u : (v & ((1u << valid) - 1u)));
+                iw[s] = v;
+            }
+        }
+        // rate profile: information bit 32 w + i goes where the output stage would fetch it from
+#pragma unroll
+        for (int i = 0; i < SC_STAGE_WORDS / 64; i++) stage[lane + 64 * i] = 0u;
+        wave_sync();
+        {
+            unsigned char *base = reinterpret_cast<unsigned char *>(stage);
+            const uint32_t goff = (uint32_t)grp << 2;
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                if (s == 0 || (TW > 16 && Kw > 16)) {
+                    const uint16_t *t = asl_s + sub + 16 * s;
+#pragma unroll
+                    for (int i = 0; i < 32; i++) {
+                        const uint32_t e = t[i * TW];  // unused entries meet zero bits only
+                        atomicOr(reinterpret_cast<uint32_t *>(base + ((e & ~31u) | goff)), ((iw[s] >> i) & 1u) << (e & 31u));
+                    }
+                }
+            }
+        }
+        wave_sync();
+        uint32_t xlo = stage[16 * sub + grp], xhi = (NLOG > 9) ? stage[16 * sub + 8 + grp] : 0u;
+        wave_sync();
+        slice_transform<NLOG>(xlo, xhi, sub);  // u -> x
+        d.cg.xlo = xlo;
+        d.cg.xhi = xhi;
+        decode_static<PolarStaticProfile, NLOG, 0, 0>(d, nullptr, rc);
+        sc_reg_epilogue<NLOG>(d.root, stage, asl_s, nullptr, fc, active, lane, K, Kw, nullptr, K, &acc, true, iw[0], iw[1]);
+    }
+    err_acc_flush(acc, counters);
+}
+#endif
 #endif

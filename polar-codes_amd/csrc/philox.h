@@ -4,8 +4,10 @@
 // so every frame's inputs depend only on (seed, global frame index): results do not change with the
 // batch size, the chunking or the number of GPUs the frames are spread over.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 __device__ __forceinline__ uint32_t philox_vgpr(uint32_t c)
 {
@@ -53,6 +55,7 @@ template <> __device__ __forceinline__ void box_muller<float>(uint32_t a, uint32
     z1 = R * __builtin_amdgcn_sinf(u2);
 }
 
+#ifndef __HIPCC_RTC__  // the run-time compiled kernels are fp32
 template <> __device__ __forceinline__ void box_muller<double>(uint32_t a, uint32_t b, double &z0, double &z1)
 {
     double u1 = ((double)a + 0.5) * 2.3283064365386963e-10;
@@ -63,3 +66,4 @@ template <> __device__ __forceinline__ void box_muller<double>(uint32_t a, uint3
     z0 = R * c;
     z1 = R * s;
 }
+#endif

@@ -893,6 +893,23 @@ extern "C" int polar_mc_run(polar_code *c, int decoder, int L, int dtype, int fl
     HIP_TRY(hipSetDevice(ctx->device));
     if (nframes == 0) return POLAR_OK;
     const size_t es = llr_size(dtype);
+    // a code with a specialised decoder runs fp32 SC frames in one kernel, from the random bits to the counters, with no
+    // LLR buffer at all (POLAR_MC_KERNEL=staged keeps the generator -> buffer -> decoder pipeline below)
+    if (decoder == POLAR_DEC_SC && dtype == POLAR_F32 && !crc && c->static_mc_fn) {
+        const char *e = getenv("POLAR_MC_KERNEL");
+        if (!(e && e[0] == 's')) {
+            int rc;
+            if ((rc = ctx->counters.reserve(3 * sizeof(uint64_t)))) return rc;
+            uint64_t *dcnt = ctx->counters.as<uint64_t>();
+            HIP_TRY(hipMemsetAsync(dcnt, 0, 3 * sizeof(uint64_t), ctx->stream));
+            if ((rc = launch_sc_static_mc(c, nframes, N0, seed, frame0, dcnt))) return rc;
+            uint64_t h[3];
+            HIP_TRY(hipMemcpyAsync(h, dcnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            for (int i = 0; i < 3; i++) counters[i] += h[i];
+            return POLAR_OK;
+        }
+    }
     // chunks of about 4 GiB of LLRs (10^6 frames at N = 1024: long enough that the kernels' tails do not count), two buffers: chunk i+1 is generated on its own stream while chunk i is
     // decoded and counted (the decoders leave registers and issue slots free that the generator can use)
     int64_t chunk = std::max<int64_t>(1024, ((int64_t)1 << 32) / ((int64_t)c->N * (int64_t)es));

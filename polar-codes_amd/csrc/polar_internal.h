@@ -111,6 +111,7 @@ struct polar_code {
     // decoder compiled at run time for this rate profile (polar_code_specialize), or null
     hipModule_t static_mod = nullptr;
     hipFunction_t static_fn = nullptr;
+    hipFunction_t static_mc_fn = nullptr;  // generate + decode + count in one kernel (absent below N = 128)
     polar_launch_info last{};
 };
 
@@ -142,6 +143,7 @@ int launch_crc_filter(polar_code *c, const uint32_t *info_hat, uint32_t *rows, u
                       uint8_t *crc_ok, int32_t *last_seq, int64_t B);
 
 int launch_sc_static(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B);
+int launch_sc_static_mc(polar_code *c, int64_t B, double N0, uint64_t seed, uint64_t frame0, uint64_t *counters_dev);
 
 // timing bracket around the dominant kernel of a call
 struct LaunchTimer {

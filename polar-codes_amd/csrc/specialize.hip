@@ -1,5 +1,6 @@
 // Run-time specialisation: builds kernels_sc_static.h for one rate profile with hiprtc and launches the result.
 #include <hip/hiprtc.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -9,7 +10,7 @@
 #include <vector>
 
 #include "polar_internal.h"
-#include "build/embedded_sources.h"  // POLAR_SRC_decode_common, POLAR_SRC_reg_common, POLAR_SRC_kernels_sc_static
+#include "build/embedded_sources.h"  // POLAR_SRC_decode_common, POLAR_SRC_reg_common, POLAR_SRC_philox, POLAR_SRC_kernels_sc_static
 
 static int compile_static(const uint8_t *mask, int N, const char *arch, std::vector<char> &code)
 {
@@ -29,10 +30,10 @@ static int compile_static(const uint8_t *mask, int N, const char *arch, std::vec
         src += buf;
     }
     src += "\n#include \"kernels_sc_static.h\"\n";
-    const char *names[] = {"decode_common.h", "reg_common.h", "kernels_sc_static.h"};
-    const char *texts[] = {POLAR_SRC_decode_common, POLAR_SRC_reg_common, POLAR_SRC_kernels_sc_static};
+    const char *names[] = {"decode_common.h", "reg_common.h", "philox.h", "kernels_sc_static.h"};
+    const char *texts[] = {POLAR_SRC_decode_common, POLAR_SRC_reg_common, POLAR_SRC_philox, POLAR_SRC_kernels_sc_static};
     hiprtcProgram prog;
-    hiprtcResult r = hiprtcCreateProgram(&prog, src.c_str(), "polar_static.hip", 3, texts, names);
+    hiprtcResult r = hiprtcCreateProgram(&prog, src.c_str(), "polar_static.hip", 4, texts, names);
     if (r != HIPRTC_SUCCESS) {
         polar_set_error("hiprtcCreateProgram failed: %s", hiprtcGetErrorString(r));
         return POLAR_EUNSUPPORTED;
@@ -100,6 +101,10 @@ extern "C" int polar_code_specialize(polar_code *c)
     if ((rc = compile_static(c->mask.data(), c->N, arch.c_str(), code))) return rc;
     HIP_TRY(hipModuleLoadData(&c->static_mod, code.data()));
     HIP_TRY(hipModuleGetFunction(&c->static_fn, c->static_mod, "sc_static_kernel"));
+    if (hipModuleGetFunction(&c->static_mc_fn, c->static_mod, "sc_static_mc_kernel") != hipSuccess) {
+        c->static_mc_fn = nullptr;  // short codes have no fused Monte-Carlo kernel
+        (void)hipGetLastError();
+    }
     return POLAR_OK;
 }
 
@@ -129,6 +134,38 @@ int launch_sc_static(polar_code *c, const void *llr, uint32_t *info_hat, int64_t
     c->last.lanes_per_frame = 16;
     int lds_bytes = 0;
     (void)hipFuncGetAttribute(&lds_bytes, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, c->static_fn);
+    c->last.lds_bytes_per_block = lds_bytes;
+    c->last.block_threads = 64 * WAVES;
+    c->last.grid_blocks = (int)grid;
+    c->last.last_ms = ms;
+    return POLAR_OK;
+}
+
+int launch_sc_static_mc(polar_code *c, int64_t B, double N0, uint64_t seed, uint64_t frame0, uint64_t *counters_dev)
+{
+    if (B == 0) return POLAR_OK;
+    polar_ctx *ctx = c->ctx;
+    constexpr int WAVES = 4;
+    int occ = 0;
+    HIP_TRY(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, c->static_mc_fn, 64 * WAVES, 0));
+    if (occ < 1) occ = 1;
+    const int64_t per_block = 4 * WAVES;
+    const int64_t need = (B + per_block - 1) / per_block;
+    const int64_t grid = std::min<int64_t>(need, (int64_t)ctx->num_cus * occ * 8);
+    const void *a_asl = c->d_Asl;
+    long long a_B = (long long)B;
+    int a_K = c->K, a_Kw = c->Kw;
+    float a_sigma = (float)sqrt(N0 / 2.0), a_gain = (float)(4.0 / N0);  // as launch_gen_frames passes them
+    unsigned long long a_seed = seed, a_frame0 = frame0;
+    void *a_cnt = counters_dev;
+    void *args[] = {&a_asl, &a_B, &a_K, &a_Kw, &a_sigma, &a_gain, &a_seed, &a_frame0, &a_cnt};
+    LaunchTimer tm(ctx);
+    HIP_TRY(hipModuleLaunchKernel(c->static_mc_fn, (unsigned)grid, 1, 1, 64 * WAVES, 1, 1, 0, ctx->stream, args, nullptr));
+    float ms = tm.stop();
+    snprintf(c->last.kernel, sizeof(c->last.kernel), "sc_static_mc_kernel<%d>", c->n);
+    c->last.lanes_per_frame = 16;
+    int lds_bytes = 0;
+    (void)hipFuncGetAttribute(&lds_bytes, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, c->static_mc_fn);
     c->last.lds_bytes_per_block = lds_bytes;
     c->last.block_threads = 64 * WAVES;
     c->last.grid_blocks = (int)grid;

@@ -275,6 +275,29 @@ def test_sc_signed_zeros_and_extremes(monkeypatch, N, K):
     assert np.array_equal(spec, gen)
 
 
+@pytest.mark.parametrize("N,K", [(128, 64), (256, 31), (512, 300), (1024, 512), (1024, 800)])
+def test_mc_fused_kernel_equals_staged_pipeline(monkeypatch, N, K):
+    """The single kernel that draws the bits, encodes, adds the noise, decodes and counts (specialised codes, fp32 SC)
+    against generator -> LLR buffer -> decoder (whose parts are held to the oracle by the tests above), for frame counts
+    that do not fill the last wavefront and frame offsets beyond 32 bits.  The counters must be identical."""
+    mask = pcf.degaBuild(N, K, 2.0)
+    code = _native.Code(_native.default_ctx(), mask)
+    code.specialize()
+    n0 = n0_of(1.5, K / N)
+    for seed, frame0, nframes in ((3, 0, 1), (3, 5, 37), (11, 1 << 33, 20011)):
+        fused = code.mc_run(_native.DEC_SC, 1, np.float32, n0, seed, frame0, nframes).tolist()
+        assert code.last_launch()["kernel"].startswith("sc_static_mc_kernel"), code.last_launch()
+        monkeypatch.setenv("POLAR_MC_KERNEL", "staged")
+        staged = code.mc_run(_native.DEC_SC, 1, np.float32, n0, seed, frame0, nframes).tolist()
+        assert code.last_launch()["kernel"].startswith("sc_static_kernel"), code.last_launch()
+        monkeypatch.delenv("POLAR_MC_KERNEL")
+        assert fused == staged and fused[0] == nframes, (seed, frame0, nframes, fused, staged)
+    # frames split over calls add up (what ranks and rounds of the simulator rely on)
+    a = code.mc_run(_native.DEC_SC, 1, np.float32, n0, 5, 100, 3000)
+    b = code.mc_run(_native.DEC_SC, 1, np.float32, n0, 5, 100, 1234) + code.mc_run(_native.DEC_SC, 1, np.float32, n0, 5, 1334, 1766)
+    assert a.tolist() == b.tolist()
+
+
 def n0_of(snr_db, rate):
     return 1.0 / (rate * 10 ** (snr_db / 10))
 
