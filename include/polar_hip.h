@@ -76,7 +76,9 @@ int polar_code_schedule_len(const polar_code *code, int which);
 /* Compiles, with the HIP run-time compiler, an SC decoder specialised for this code's rate profile (an
  * "unrolled" decoder: the whole tree walk becomes straight-line code) and uses it from then on for
  * polar_sc_decode* / polar_mc_run calls with POLAR_SC_FAST, fp32 LLRs and information-bit output only.
- * Same decisions as the generic kernels.  32 <= N <= 1024, 0 < K < N.  Takes seconds; meant for long runs
+ * Same decisions as the generic kernels.  32 <= N <= 1024, 0 < K < N.  For N >= 128 it also builds the kernel
+ * that polar_mc_run then uses for such runs: the whole frame loop (random bits, encoder, channel, decoder,
+ * error count) in one kernel with no LLR buffer, counters identical to the staged path.  Takes about a second; meant for long runs
  * over one code, like the per-code set-up of PolarCode.__init__ (cn/polarCode.py:116-157).  No counterpart
  * in the reference.  polar_static_compile_check is the host-only part (no GPU needed): it compiles for `arch`
  * (e.g. "gfx950") and returns the size of the code object in bytes, or a negative error code. */

@@ -895,7 +895,7 @@ extern "C" int polar_mc_run(polar_code *c, int decoder, int L, int dtype, int fl
     const size_t es = llr_size(dtype);
     // a code with a specialised decoder runs fp32 SC frames in one kernel, from the random bits to the counters, with no
     // LLR buffer at all (POLAR_MC_KERNEL=staged keeps the generator -> buffer -> decoder pipeline below)
-    if (decoder == POLAR_DEC_SC && dtype == POLAR_F32 && !crc && c->static_mc_fn) {
+    if (decoder == POLAR_DEC_SC && dtype == POLAR_F32 && (flags & POLAR_SC_FAST) && !crc && c->static_mc_fn) {
         const char *e = getenv("POLAR_MC_KERNEL");
         if (!(e && e[0] == 's')) {
             int rc;
