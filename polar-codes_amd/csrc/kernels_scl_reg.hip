@@ -66,11 +66,13 @@ __device__ __forceinline__ float branch_metric_fast(float v, uint32_t u)
 // Small per-path state that moves between lane groups at a fork.
 struct PathState {
     float pm;
-    uint32_t ownL;   // 3 bits per level l (index l - 3): position whose registers hold my level-l LLRs
+    uint32_t ownL;   // 3 bits per level l (index l - 3): position whose registers hold my level-l LLRs; bits 24..26: see XB
     uint32_t ownP;   // same for the left-child partial sums of level l
     float v[3];      // my element of the LLRs of the enclosing 8-, 4- and 2-leaf nodes, until their g has run
-    uint32_t xb;     // bit I: partial-sum bit of the finished left child of the enclosing node I
+    // bit XB + I of ownL: partial-sum bit of the finished left child of the enclosing node I (one word less to move at a fork)
 };
+
+constexpr int XB = 24;
 
 struct LaneConst {
     int lane, p, q, e;
@@ -186,7 +188,6 @@ template <int NLOG> struct SclReg {
         st.pm = bperm_f(cpm, par * 8 + 4 * (int)b + (lc.q & 3));  // lanes q >= 4 hold the u=1 candidate metric
         st.ownL = bperm_u(st.ownL, src);
         st.ownP = bperm_u(st.ownP, src);
-        st.xb = bperm_u(st.xb, src);
 #pragma unroll
         for (int i = 0; i < 3; i++)
             if ((LIVE >> i) & 1u) st.v[i] = bperm_f(st.v[i], src);
@@ -280,12 +281,12 @@ template <int NLOG> struct SclReg {
             st.v[I] = v;  // forks inside the left child move it along with the path
             const float vl = f_fast(v, o);
             const uint32_t xl = sub<P / 2, LIVE | (1u << I)>(vl, mask & HALF, lc, surv);
-            st.xb = (st.xb & ~(1u << I)) | (xl << I);
+            st.ownL = (st.ownL & ~(1u << (XB + I))) | (xl << (XB + I));
             // g: the lanes of the lower half hold lo and apply the sign, then every lane adds its partner's value
             const float t = flip_sign(st.v[I], xl & lc.lowmask[I]);
             const float vr = t + partner8<P>(t);
             const uint32_t xr = sub<P / 2, LIVE>(vr, (mask >> (P / 2)) & HALF, lc, surv);
-            const uint32_t xl_now = (st.xb >> I) & 1u;  // the left result of whoever sits here now
+            const uint32_t xl_now = (st.ownL >> (XB + I)) & 1u;  // the left result of whoever sits here now
             return xr ^ (xl_now & lc.lowmask[I]);
         }
     }
@@ -351,7 +352,6 @@ __global__ void __launch_bounds__(64, 2) scl_reg_kernel(const float *__restrict_
         d.a0 = d.a1 = d.b0 = d.b1 = d.r0 = d.r1 = 0;
         d.st.pm = 0.0f;
         d.st.ownL = d.st.ownP = 0u;
-        d.st.xb = 0u;
 #pragma unroll
         for (int i = 0; i < 3; i++) d.st.v[i] = 0.0f;
         d.Lcur = 1;
