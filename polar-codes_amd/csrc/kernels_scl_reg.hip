@@ -80,9 +80,56 @@ struct LaneConst {
     uint32_t lowmask[3];
 };
 
+// At N = 1024 a path's slice is 128 LLRs per lane; with all of them in registers two wavefronts fit on a SIMD, and the
+// kernel is bound by the latency of one wavefront's instruction stream (its rate is proportional to the wavefronts
+// per CU).  The two widest levels therefore live elsewhere: level 9 (64 values per lane, touched by four steps per
+// frame) in a per-workgroup slab of global memory, level 8 (32 values) in LDS, each lane-major ([j][lane]) so that a
+// step is 64 coalesced lanes; the registers keep levels 3 .. 7 and a third wavefront fits.
+template <int NLOG> struct SclStore {
+    static constexpr int GLOBAL_LEVEL = NLOG == 10 ? 9 : 99;
+    static constexpr int LDS_LEVEL = NLOG == 10 ? 8 : 99;
+    static constexpr int REG_VALUES = NLOG == 10 ? 32 : (1 << (NLOG - 3));
+    static constexpr int LDS_VALUES = NLOG == 10 ? 32 * 64 : 1;       // floats per wavefront
+    static constexpr int GLOBAL_VALUES = NLOG == 10 ? 64 * 64 : 0;    // floats per wavefront
+};
+
 template <int NLOG> struct SclReg {
-    static constexpr int S = 1 << (NLOG - 3);
-    float R[S];           // level l (3 <= l < NLOG): 2^(l-3) values at offset 2^(l-3)
+    static constexpr int S = SclStore<NLOG>::REG_VALUES;
+    float R[S];           // level l (3 <= l < NLOG) kept in registers: 2^(l-3) values at offset 2^(l-3)
+    float *lv_lds;        // the LDS level of this wavefront, + my lane
+    float *lv_glb;        // the global level of this wavefront, + my lane
+    int my_lane;
+
+    // element j of my level L / of the level-L values that the lanes `src` (owner position * 8 + q) hold / store
+    template <int L> __device__ __forceinline__ float ld_own(int j) const
+    {
+        if constexpr (L == SclStore<NLOG>::GLOBAL_LEVEL) return lv_glb[j * 64];
+        else if constexpr (L == SclStore<NLOG>::LDS_LEVEL) return lv_lds[j * 64];
+        else return R[(1 << (L - 3)) + j];
+    }
+    template <int L> __device__ __forceinline__ float ld_from(int j, int src) const
+    {
+        if constexpr (L == SclStore<NLOG>::GLOBAL_LEVEL) return lv_glb[j * 64 + (src - my_lane)];
+        else if constexpr (L == SclStore<NLOG>::LDS_LEVEL) return lv_lds[j * 64 + (src - my_lane)];
+        else return bperm_f(R[(1 << (L - 3)) + j], src);
+    }
+    template <int L> __device__ __forceinline__ void st_own(int j, float v)
+    {
+        if constexpr (L == SclStore<NLOG>::GLOBAL_LEVEL) lv_glb[j * 64] = v;
+        else if constexpr (L == SclStore<NLOG>::LDS_LEVEL) lv_lds[j * 64] = v;
+        else R[(1 << (L - 3)) + j] = v;
+    }
+    // after a level held in memory was written and before other lanes read it
+    template <int L> static __device__ __forceinline__ void level_written()
+    {
+        if constexpr (L == SclStore<NLOG>::GLOBAL_LEVEL) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        } else if constexpr (L == SclStore<NLOG>::LDS_LEVEL) {
+            wave_sync();
+        }
+    }
     uint64_t a0, a1;      // plane 0 partial sums: levels with <= 32 bits per lane in a0 (offset = bit count), 64-bit level in a1
     uint64_t b0, b1;      // plane 1
     uint64_t r0, r1;      // root (S bits)
@@ -109,7 +156,7 @@ template <int NLOG> struct SclReg {
         return (row & ~(7u << (3 * (lev - 3)))) | (p << (3 * (lev - 3)));
     }
 
-    // f: level LEV -> LEV-1 from my own registers (or the channel at the top)
+    // f: level LEV -> LEV-1 from my own values (or the channel at the top)
     template <int LEV> __device__ __forceinline__ void step_f(const float *chan_lane, const LaneConst &lc)
     {
         constexpr int c = 1 << (LEV - 4);
@@ -120,11 +167,12 @@ template <int NLOG> struct SclReg {
                 a = chan_lane[8 * j];
                 b = chan_lane[8 * (j + c)];
             } else {
-                a = R[2 * c + j];
-                b = R[3 * c + j];
+                a = ld_own<LEV>(j);
+                b = ld_own<LEV>(c + j);
             }
-            R[c + j] = f_fast(a, b);
+            st_own<LEV - 1>(j, f_fast(a, b));
         }
+        level_written<LEV - 1>();
         st.ownL = own_set(st.ownL, LEV - 1, (uint32_t)lc.p);
     }
     // g: operands and the left child's partial sums come from their owners' lanes
@@ -137,7 +185,7 @@ template <int NLOG> struct SclReg {
         else if constexpr (c >= 16) bits = (bperm_u64(a0, srcP) >> c) & (((uint64_t)1 << c) - 1);
         else bits = (uint64_t)((bperm_u((uint32_t)a0, srcP) >> c) & ((1u << c) - 1u));
         const int srcL = (LEV == NLOG) ? 0 : (int)own_get(st.ownL, LEV) * 8 + lc.q;
-        // operands live at offsets 2c..4c-1, results go to c..2c-1: no lane overwrites what another still reads
+        // operands are level LEV, results level LEV-1: no lane overwrites what another still reads
 #pragma unroll
         for (int j = 0; j < c; j++) {
             float a, b;
@@ -145,11 +193,12 @@ template <int NLOG> struct SclReg {
                 a = chan_lane[8 * j];
                 b = chan_lane[8 * (j + c)];
             } else {
-                a = bperm_f(R[2 * c + j], srcL);
-                b = bperm_f(R[3 * c + j], srcL);
+                a = ld_from<LEV>(j, srcL);
+                b = ld_from<LEV>(c + j, srcL);
             }
-            R[c + j] = g_fast(a, b, (uint32_t)(bits >> j) & 1u);
+            st_own<LEV - 1>(j, g_fast(a, b, (uint32_t)(bits >> j) & 1u));
         }
+        level_written<LEV - 1>();
         st.ownL = own_set(st.ownL, LEV - 1, (uint32_t)lc.p);
     }
     template <int LEV> __device__ __forceinline__ void combine(int plane, const LaneConst &lc)
@@ -319,20 +368,17 @@ __device__ __forceinline__ void scl_node(SclReg<NLOG> &d, uint32_t maskv, const 
 }
 
 template <int NLOG>
-__global__ void __launch_bounds__(64, 2) scl_reg_kernel(const float *__restrict__ llr, const uint32_t *__restrict__ maskw,
-                                                        const uint32_t *__restrict__ Asl8, const uint32_t *__restrict__ crcS,
+__global__ void __launch_bounds__(64, NLOG == 10 ? 3 : 2) scl_reg_kernel(const float *__restrict__ llr, const uint32_t *__restrict__ maskw,
+                                                        const uint16_t *__restrict__ Asl8, const uint32_t *__restrict__ crcS,
                                                         const uint32_t *__restrict__ truth, uint32_t *__restrict__ info_hat, int64_t B,
-                                                        int K, int Kw)
+                                                        int K, int Kw, float *__restrict__ slab)
 {
     __shared__ uint32_t surv[8];
     __shared__ uint32_t stage[64 * 4];  // 8 paths x 8 lanes x 128-bit slice of u_hat
     constexpr int N = 1 << NLOG;
-    __shared__ uint32_t asl_s[N];       // the gather table of the output stage (and the CRC remainders) in LDS
-    __shared__ uint32_t crc_s[N];
-    for (int k = threadIdx.x; k < K; k += 64) {
-        asl_s[k] = Asl8[k];
-        if (crcS) crc_s[k] = crcS[k];
-    }
+    __shared__ uint16_t asl_s[N];       // the gather table of the output stage (the CRC remainders stay in global memory)
+    __shared__ float lvl_s[SclStore<NLOG>::LDS_VALUES];
+    for (int k = threadIdx.x; k < K; k += 64) asl_s[k] = Asl8[k];
     wave_sync();
     LaneConst lc;
     lc.lane = threadIdx.x;
@@ -346,6 +392,9 @@ __global__ void __launch_bounds__(64, 2) scl_reg_kernel(const float *__restrict_
     }
     const uint32_t maskv = maskw[(lc.lane & 31) < (N / 32) ? (lc.lane & 31) : 0];
     SclReg<NLOG> d;
+    d.my_lane = lc.lane;
+    d.lv_lds = lvl_s + lc.lane;
+    d.lv_glb = slab + (size_t)blockIdx.x * SclStore<NLOG>::GLOBAL_VALUES + lc.lane;
 
     for (int64_t f = blockIdx.x; f < B; f += gridDim.x) {
         const float *chan_lane = llr + f * N + lc.e;
@@ -397,7 +446,7 @@ __global__ void __launch_bounds__(64, 2) scl_reg_kernel(const float *__restrict_
                 [&](int k) {
                     const uint32_t a = asl_s[k];  // (lane-in-path << 7) | bit
                     const bool bit = ((mine[(a >> 7) * 4 + ((a >> 5) & 3u)] >> (a & 31u)) & 1u) != 0u;
-                    if (crcS && bit) syn ^= crc_s[k];
+                    if (crcS && bit) syn ^= crcS[k];
                     return bit;
                 },
                 [&](int wi, uint32_t v) {
@@ -459,18 +508,26 @@ static int launch_scl_reg_t(polar_code *c, const void *llr, uint32_t *info_hat, 
 {
     polar_ctx *ctx = c->ctx;
     auto kern = scl_reg_kernel<NLOG>;
+    // POLAR_SCL_LDSPAD (bytes of unused dynamic LDS per wavefront) lowers the occupancy for experiments
+    const char *pe = getenv("POLAR_SCL_LDSPAD");
+    const size_t pad = pe ? (size_t)atoi(pe) : 0;
+    if (pad > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
     int occ = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, pad));
     if (occ < 1) occ = 1;
     int64_t grid = std::min<int64_t>(B, (int64_t)ctx->num_cus * occ * 8);
+    // one slab per workgroup for the level that lives in global memory (N = 1024: 16 KB each)
+    int rc;
+    if ((rc = ctx->scl_slab.reserve(std::max<size_t>(4, (size_t)grid * SclStore<NLOG>::GLOBAL_VALUES * sizeof(float))))) return rc;
     LaunchTimer tm(ctx);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), 0, ctx->stream, (const float *)llr, (const uint32_t *)c->d_maskw,
-                       (const uint32_t *)c->d_Asl8, crc ? (const uint32_t *)c->d_crcS : nullptr, truth, info_hat, B, c->K, c->Kw);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), pad, ctx->stream, (const float *)llr, (const uint32_t *)c->d_maskw,
+                       (const uint16_t *)c->d_Asl8, crc ? (const uint32_t *)c->d_crcS : nullptr, truth, info_hat, B, c->K, c->Kw,
+                       ctx->scl_slab.as<float>());
     HIP_TRY(hipGetLastError());
     float ms = tm.stop();
     snprintf(c->last.kernel, sizeof(c->last.kernel), "scl_reg_kernel<%d>/L8", NLOG);
     c->last.lanes_per_frame = 64;
-    c->last.lds_bytes_per_block = 32 + 1024;
+    c->last.lds_bytes_per_block = 32 + 1024 + 2 * c->N + 4 * SclStore<NLOG>::LDS_VALUES;
     c->last.block_threads = 64;
     c->last.grid_blocks = (int)grid;
     c->last.last_ms = ms;

@@ -212,10 +212,10 @@ extern "C" int polar_code_create(polar_ctx *ctx, int N, const uint8_t *mask, pol
             Asl[at >> 1] |= e << (16 * (at & 1));
         }
     }
-    std::vector<uint32_t> Asl8;
-    for (uint32_t pos : A) {
-        uint32_t e = pos & 7u, q = e < 4 ? e : 11 - e;
-        Asl8.push_back((q << 7) | (pos >> 3));
+    std::vector<uint32_t> Asl8((A.size() + 1) / 2, 0u);  // 16-bit entries, two per word
+    for (size_t k = 0; k < A.size(); k++) {
+        const uint32_t pos = A[k], e = pos & 7u, q = e < 4 ? e : 11 - e;
+        if (N <= 1024) Asl8[k >> 1] |= ((q << 7) | (pos >> 3)) << (16 * (k & 1));
     }
     std::vector<uint32_t> pid16(64, 0);
     for (int b = 0; b < N / 16 && b < 64; b++) {

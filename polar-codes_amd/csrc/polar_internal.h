@@ -74,7 +74,7 @@ struct polar_ctx {
     hipStream_t gen_stream = nullptr;
     hipEvent_t gen_done[2] = {nullptr, nullptr}, dec_done[2] = {nullptr, nullptr};
     // staging / scratch
-    DevBuf in_bytes, out_bytes, in_words, out_words, llr_buf, aux_buf, aux2_buf, pm_buf, counters, mc_info, mc_hat;
+    DevBuf in_bytes, out_bytes, in_words, out_words, llr_buf, aux_buf, aux2_buf, pm_buf, counters, mc_info, mc_hat, scl_slab;
     DevBuf mc_llr2, mc_info2;  // second buffers of the Monte-Carlo pipeline
     DevBuf flip_rows, flip_ctr, flip_small;  // failing-frame list, {work counter, row count}, per-frame side outputs
 };
