@@ -10,8 +10,9 @@
 // whose registers hold each of its LLR levels and each of its left-child partial-sum levels.  All paths
 // rewrite a level in lockstep, each into its own registers, so an owner's registers stay valid until
 // every path has replaced that level.  Right-child g operations and combines fetch their operands from
-// the owner's lanes with ds_bpermute; a fork or prune only moves the small per-path state (metric, owner
-// rows, the six live values and three live bits of the 8-leaf subtree being decoded).
+// the owner's lanes with ds_bpermute (or, for a level kept in memory, from the owner's lanes' slots); a fork or
+// prune only moves the small per-path state (metric, owner rows, the live values and bits of the 8-leaf subtree
+// being decoded).
 //
 // Path metric and ordering follow the reference's sclDecoder / polarSCLFork: PM += 1 - log2(1 + 2^(-+Li));
 // below saturation list = originals ++ copies; at saturation the 16 candidates, ordered copies(u=1) ++
