@@ -81,7 +81,7 @@ extern "C" int polar_ctx_destroy(polar_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->in_bytes, &c->out_bytes, &c->in_words, &c->out_words, &c->llr_buf,   &c->aux_buf,  &c->aux2_buf,
                       &c->pm_buf,   &c->counters,  &c->mc_info,  &c->mc_hat,    &c->flip_rows, &c->flip_ctr, &c->flip_small,
-                      &c->mc_llr2,  &c->mc_info2};
+                      &c->mc_llr2,  &c->mc_info2,  &c->scl_slab};
     for (DevBuf *b : bufs) b->release();
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
