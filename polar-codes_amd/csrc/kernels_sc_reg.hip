@@ -22,58 +22,8 @@
 #include "decode_common.h"
 #include "reg_common.h"
 #include "kernels_sc_static.h"
+#include "kernels_sc_node.h"
 #include "polar_internal.h"
-
-// Node classes per tree level (bit i of level l = node i of that level, l = 4 .. 10 -> index l-4):
-// r0 = every leaf frozen, r1 = every leaf information.  In plain (non-fast) mode both are all zero.
-struct NodeClasses {
-    uint64_t r0[7];
-    uint64_t r1[7];
-};
-
-// A mixed node at level LEV >= 5, index idx within its level.  The two children are visited by a
-// two-trip loop that is deliberately NOT unrolled: every level's code then exists exactly once in the
-// program (F, G, rate-0, rate-1, combine), the recursion is a fixed nest of NLOG-4 loops, and the
-// register array keeps fixed homes.
-template <int LEV, int NLOG, bool FAST, typename T>
-__device__ __forceinline__ void decode_node(RegDec<T, NLOG> &d, const NodeClasses &nc, uint32_t maskv, uint32_t pidv,
-                                            const T *chan_lane, uint32_t idx, int plane, const RowConst &rc)
-{
-#pragma nounroll
-    for (uint32_t h = 0; h < 2; h++) {
-        if (h == 0) d.template step<LEV, false>(chan_lane);
-        else d.template step<LEV, true>(chan_lane);
-        const uint32_t cidx = 2 * idx + h;
-        const bool is0 = FAST && ((nc.r0[LEV - 5] >> cidx) & 1ull);
-        const bool is1 = FAST && ((nc.r1[LEV - 5] >> cidx) & 1ull);
-        if (is0) {
-            d.template rate0<LEV - 1>((int)h);
-        } else if (is1) {
-            d.template rate1<LEV - 1>((int)h);
-        } else {
-            if constexpr (LEV - 1 == 4) {
-                // lane i of maskv holds word i of the rate profile; the index is wave-uniform
-                const uint32_t mw = (uint32_t)__builtin_amdgcn_readlane((int)maskv, (int)(cidx >> 1));
-                const uint32_t m16 = (mw >> (16 * (cidx & 1))) & 0xFFFFu;
-                uint32_t x;
-                // lane i of pidv names the profile of 16-leaf node i (0: none of the compiled ones)
-                const uint32_t pid = FAST ? (uint32_t)__builtin_amdgcn_readlane((int)pidv, (int)cidx) : 0u;
-                switch (pid) {
-#define POLAR_CASE16(ID, MASK) \
-    case ID: x = sub_node_s<16, MASK>(d.R[1], rc) >> 31; break;
-                    POLAR_PROFILES16(POLAR_CASE16)
-#undef POLAR_CASE16
-                default: x = sub_node<16, FAST>(d.R[1], m16, rc); break;
-                }
-                if (h) d.ps1 = (d.ps1 & ~(ps_t)2) | ((ps_t)x << 1);
-                else d.ps0 = (d.ps0 & ~(ps_t)2) | ((ps_t)x << 1);
-            } else {
-                decode_node<LEV - 1, NLOG, FAST>(d, nc, maskv, pidv, chan_lane, cidx, (int)h, rc);
-            }
-        }
-    }
-    d.template combine<LEV>(plane);
-}
 
 template <typename T, int NLOG, bool FAST>
 __global__ void __launch_bounds__(64, 4) sc_reg_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, NodeClasses nc,

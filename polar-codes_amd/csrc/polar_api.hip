@@ -217,8 +217,8 @@ extern "C" int polar_code_create(polar_ctx *ctx, int N, const uint8_t *mask, pol
         const uint32_t pos = A[k], e = pos & 7u, q = e < 4 ? e : 11 - e;
         if (N <= 1024) Asl8[k >> 1] |= ((q << 7) | (pos >> 3)) << (16 * (k & 1));
     }
-    std::vector<uint32_t> pid16(64, 0);
-    for (int b = 0; b < N / 16 && b < 64; b++) {
+    std::vector<uint32_t> pid16(std::max(64, N / 16), 0);
+    for (int b = 0; b < N / 16; b++) {
         uint32_t m16 = 0;
         for (int i = 0; i < 16; i++) m16 |= (uint32_t)c->mask[16 * b + i] << i;
         pid16[b] = sc_reg_profile_id(m16);
@@ -257,6 +257,7 @@ extern "C" int polar_code_destroy(polar_code *c)
     for (void *p : qs)
         if (p) (void)hipFree(p);
     if (c->static_mod) (void)hipModuleUnload(c->static_mod);
+    sc_big_release(c);
     delete c;
     return POLAR_OK;
 }

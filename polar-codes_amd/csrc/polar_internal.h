@@ -91,7 +91,8 @@ struct polar_code {
     uint32_t *d_A = nullptr;       // K info positions, ascending
     uint32_t *d_sched[4] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t *d_Asl8 = nullptr;    // same for the 8-lanes-per-path layout: (lane-in-path << 7) | bit
-    uint32_t *d_pid16 = nullptr;   // 64 words: compiled-profile number of each 16-leaf node (register SC kernel)
+    uint32_t *d_pid16 = nullptr;   // max(64, N/16) words: compiled-profile number of each 16-leaf node (register SC kernels)
+    void *big_tables = nullptr;    // tables of the long-code SC kernel, built on first use (kernels_sc_big.hip)
     uint32_t *d_Asl = nullptr;     // gather table of the register SC kernels: [bit i][word w] -> (staged word << 5) | bit
     // CRC (0 = none): generator with leading term, degree, and the two linear maps of the remainder
     uint64_t crc_poly = 0;
@@ -128,6 +129,9 @@ int launch_sc_decode(polar_code *c, const void *llr, int dtype, uint32_t *info_h
 uint32_t sc_reg_profile_id(uint32_t m16);
 bool sc_reg_supported(const polar_code *c, int dtype, const void *u_hat, const void *dec_llr);
 int launch_sc_reg(polar_code *c, const void *llr, int dtype, uint32_t *info_hat, int64_t B, int flags);
+bool sc_big_supported(const polar_code *c, int dtype, const void *u_hat, const void *dec_llr, int flags);
+int launch_sc_big(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B);
+void sc_big_release(polar_code *c);
 bool scl_reg_supported(const polar_code *c, int dtype, int L, const void *pm, const void *u_hat_all);
 // truth (packed [B x Kw], or NULL): genie-aided choice of the output path
 int launch_scl_reg(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, bool crc, const uint32_t *truth);

@@ -298,6 +298,30 @@ def test_mc_fused_kernel_equals_staged_pipeline(monkeypatch, N, K):
     assert a.tolist() == b.tolist()
 
 
+@pytest.mark.parametrize("N,K", [(2048, 1000), (2048, 37), (4096, 3000), (8192, 4096), (16384, 8192), (32768, 20000)])
+def test_sc_long_codes_slab_kernel_vs_oracle_and_lds_kernel(monkeypatch, N, K):
+    """Codes longer than 1024 in fp32: the kernel that keeps the wide levels in a global slab and decodes 1024-leaf
+    subtrees in registers, against the oracle (bit-exact) and the LDS-staged kernel, ragged batch sizes included."""
+    mask = pcf.degaBuild(N, K, 2.0)
+    code = _native.Code(_native.default_ctx(), mask)
+    rs = np.random.RandomState(N + K)
+    B = 21
+    x = oracle.polar_encode(rs.randint(0, 2, size=(B, K)), mask)
+    llr = code.channel_llr(x, n0_of(1.0, K / N), 3, 0, np.float32)
+    got, _, _ = code.sc_decode(llr, fast=True)
+    assert code.last_launch()["kernel"].startswith("sc_big_kernel"), code.last_launch()
+    nref = 4 if N <= 8192 else 2
+    ref = np.stack([oracle.extract(oracle.sc_decode(llr[b], mask), mask) for b in range(nref)])
+    assert np.array_equal(got[:nref], ref)
+    monkeypatch.setenv("POLAR_SC_KERNEL", "lds")
+    lds, _, _ = code.sc_decode(llr, fast=True)
+    assert code.last_launch()["kernel"].startswith("sc_decode_kernel")
+    monkeypatch.delenv("POLAR_SC_KERNEL")
+    assert np.array_equal(got, lds)
+    one, _, _ = code.sc_decode(llr[:1], fast=True)
+    assert np.array_equal(one, got[:1])
+
+
 def n0_of(snr_db, rate):
     return 1.0 / (rate * 10 ** (snr_db / 10))
 
