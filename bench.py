@@ -321,7 +321,8 @@ def main():
             l16k = torch.empty((nb, 16384), dtype=torch.float32, device=dev)
             c16k.gen_frames_dev(None, l16k.data_ptr(), np.float32, ch.noisePower, seed, 0, nb)
             h16k = torch.empty((nb, c16k.Kw), dtype=torch.int32, device=dev)
-            c16k.sc_decode_dev(l16k.data_ptr(), np.float32, h16k.data_ptr(), nb, fast=True)
+            for _ in range(2):  # the first call builds the long-code tables and sizes the slab
+                c16k.sc_decode_dev(l16k.data_ptr(), np.float32, h16k.data_ptr(), nb, fast=True)
             li = c16k.last_launch()
             extras["sc_16384_8192"] = {"frames_per_s": nb / (li["last_ms"] * 1e-3), "info_mbps": nb * 8192 / (li["last_ms"] * 1e-3) / 1e6,
                                        "kernel": li["kernel"], "kernel_ms": li["last_ms"], "frames": nb,
