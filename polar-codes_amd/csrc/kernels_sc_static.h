@@ -546,8 +546,9 @@ extern "C" __global__ void __launch_bounds__(64 * SC_STATIC_WAVES, POLAR_STATIC_
 {
     constexpr int NLOG = POLAR_STATIC_NLOG;
     constexpr int PAIRS = PolarStaticShape::PAIRS;
-    constexpr int KEEP = PolarStaticShape::KEEP;
-    constexpr int KL = PAIRS - KEEP;  // nothing can be read again: what is not in registers waits in LDS
+    // nothing can be read again: what is not in registers waits in LDS, at most 16 pairs (8 KB per wavefront) of it
+    constexpr int KL = (PAIRS - PolarStaticShape::KEEP) < 16 ? (PAIRS - PolarStaticShape::KEEP) : 16;
+    constexpr int KEEP = PAIRS - KL;
     constexpr int KEPT = 2 * KL * 64;
     constexpr int TW = GatherShape<NLOG>::TW;
     __shared__ __attribute__((aligned(32))) uint32_t stage_s[SC_STATIC_WAVES * SC_STAGE_WORDS];
