@@ -4,7 +4,10 @@
 // tree level in lane k mod 16 -- with the levels of width >= 1024 in a slab of global memory per frame (level l at
 // offset 2^l - 1024, N - 1024 floats in all; it stays in the L2 / Infinity Cache) and their partial sums beside it
 // as per-lane bit slices.  A lane only ever touches the elements of its own residue, so the slab needs no
-// synchronisation at all.  Every 1024-leaf subtree is handed to the register-resident walk of sc_reg_kernel
+// synchronisation at all, and the order of a level inside the slab is free: element 16 j + s sits at index
+// 64 (j / 4) + 4 s + j % 4, four elements of a lane side by side, so that the steps above the subtrees move 16 bytes
+// per lane and 256 contiguous bytes per frame and instruction (4-byte accesses, 64 bytes per frame, reach only two
+// thirds of the memory rate).  Every 1024-leaf subtree is handed to the register-resident walk of sc_reg_kernel
 // (kernels_sc_node.h) with the slab's level 10 as its channel; all-frozen and all-information nodes of 1024 leaves
 // and more are short-cut as in the other kernels.  The output stage transforms the sliced root (x_hat -> u_hat),
 // writes it to the slab and gathers the information bits through a table.
@@ -45,7 +48,7 @@ template <int NLOG> struct BigLayout {
 };
 
 template <int NLOG> struct BigCtx {
-    RegDec<float, 10> d;
+    RegDec<float, 10, 0, true> d;
     RowConst rc;
     BigTables t;
     float *slab;          // this frame's slab
@@ -53,26 +56,36 @@ template <int NLOG> struct BigCtx {
     int sub;
 };
 
-// f / g from level LEV to LEV-1 (LEV >= 11): elements sub + 16 j of the lane's residue
+// f / g from level LEV to LEV-1 (LEV >= 11): elements sub + 16 j of the lane's residue, four (j = 4 J .. 4 J + 3) per trip.
+// The channel itself is in natural order (4-byte accesses); every level of the slab is in the order described above.
 template <int LEV, int NLOG, bool IS_G> __device__ __forceinline__ void big_step(BigCtx<NLOG> &cx)
 {
     typedef BigLayout<NLOG> Lay;
     constexpr int half = 1 << (LEV - 1);
-    const float *in = (LEV == NLOG) ? cx.chan : cx.slab + Lay::llr_off(LEV);
-    float *out = cx.slab + Lay::llr_off(LEV - 1);
-    const uint32_t *bits = reinterpret_cast<const uint32_t *>(cx.slab) + Lay::ps_off(LEV - 1, 0);
-    constexpr int cnt = half / 16;  // elements per lane
-#pragma unroll 8
-    for (int j = 0; j < cnt; j++) {
-        const float a = in[16 * j + cx.sub], b = in[16 * j + cx.sub + half];
-        float r;
-        if (IS_G) {
-            const uint32_t w = bits[(j >> 5) * 16 + cx.sub];
-            r = g_fast(a, b, (w >> (j & 31)) & 1u);
+    float *out = cx.slab + Lay::llr_off(LEV - 1) + 4 * cx.sub;
+    const uint32_t *bits = reinterpret_cast<const uint32_t *>(cx.slab) + Lay::ps_off(LEV - 1, 0) + cx.sub;
+    constexpr int trips = half / 64;  // four elements per lane and trip
+#pragma unroll 4
+    for (int J = 0; J < trips; J++) {
+        float4 a, b;
+        if constexpr (LEV == NLOG) {
+            const float *in = cx.chan + 64 * J + cx.sub;
+            a = make_float4(in[0], in[16], in[32], in[48]);
+            b = make_float4(in[half], in[half + 16], in[half + 32], in[half + 48]);
         } else {
-            r = f_fast(a, b);
+            const float *in = cx.slab + Lay::llr_off(LEV) + 64 * J + 4 * cx.sub;
+            a = *reinterpret_cast<const float4 *>(in);
+            b = *reinterpret_cast<const float4 *>(in + half);
         }
-        out[16 * j + cx.sub] = r;
+        float4 r;
+        if (IS_G) {
+            const uint32_t w = bits[(J >> 3) * 16] >> ((4 * J) & 31);
+            r = make_float4(g_fast(a.x, b.x, w & 1u), g_fast(a.y, b.y, (w >> 1) & 1u), g_fast(a.z, b.z, (w >> 2) & 1u),
+                            g_fast(a.w, b.w, (w >> 3) & 1u));
+        } else {
+            r = make_float4(f_fast(a.x, b.x), f_fast(a.y, b.y), f_fast(a.z, b.z), f_fast(a.w, b.w));
+        }
+        *reinterpret_cast<float4 *>(out + 64 * J) = r;
     }
 }
 
@@ -91,7 +104,7 @@ template <int L, int NLOG> __device__ __forceinline__ void big_rate1(BigCtx<NLOG
     for (int w = 0; w < (1 << (L - 9)); w++) {
         uint32_t x = 0;
 #pragma unroll 8
-        for (int i = 0; i < 32; i++) x |= (v[16 * (32 * w + i) + cx.sub] < 0.0f ? 1u : 0u) << i;
+        for (int i = 0; i < 32; i++) x |= (v[64 * ((32 * w + i) >> 2) + 4 * cx.sub + (i & 3)] < 0.0f ? 1u : 0u) << i;
         ps[w * 16 + cx.sub] = x;
     }
 }
@@ -135,7 +148,7 @@ template <int LEV, int NLOG> __device__ void big_node(BigCtx<NLOG> &cx, uint32_t
             const NodeClasses nc = cx.t.sub[cidx];
             cx.d.ps0 = cx.d.ps1 = 0;
             cx.d.root = 0;
-            decode_node<10, 10, true>(cx.d, nc, maskv, pidv, cx.slab + Lay::llr_off(10) + cx.sub, 0u, 0, cx.rc);
+            decode_node<10, 10, true>(cx.d, nc, maskv, pidv, cx.slab + Lay::llr_off(10) + 4 * cx.sub, 0u, 0, cx.rc);
             uint32_t *ps = reinterpret_cast<uint32_t *>(cx.slab) + Lay::ps_off(10, (int)h);
             ps[cx.sub] = (uint32_t)cx.d.root;
             ps[16 + cx.sub] = (uint32_t)(cx.d.root >> 32);

@@ -14,9 +14,9 @@ struct NodeClasses {
 // two-trip loop that is deliberately NOT unrolled: every level's code then exists exactly once in the
 // program (F, G, rate-0, rate-1, combine), the recursion is a fixed nest of NLOG-4 loops, and the
 // register array keeps fixed homes.
-template <int LEV, int NLOG, bool FAST, typename T>
-__device__ __forceinline__ void decode_node(RegDec<T, NLOG> &d, const NodeClasses &nc, uint32_t maskv, uint32_t pidv,
-                                            const T *chan_lane, uint32_t idx, int plane, const RowConst &rc)
+template <int LEV, int NLOG, bool FAST, typename Dec>
+__device__ __forceinline__ void decode_node(Dec &d, const NodeClasses &nc, uint32_t maskv, uint32_t pidv,
+                                            const typename Dec::value_type *chan_lane, uint32_t idx, int plane, const RowConst &rc)
 {
 #pragma nounroll
     for (uint32_t h = 0; h < 2; h++) {

@@ -26,7 +26,11 @@ template <int BEGIN, int END, typename F> __device__ __forceinline__ void static
     }
 }
 
-template <typename T, int NLOG, int KEEP = 0> struct RegDec {
+// QUADS: the "channel" is an array the caller laid out for 16-byte accesses, element 16 j + lane at index
+// 64 (j / 4) + 4 lane + j % 4 (chan_lane then points at index 4 lane); otherwise element 16 j + lane at 16 j + lane.
+template <typename T, int NLOG, int KEEP = 0, bool QUADS = false> struct RegDec {
+    typedef T value_type;
+    static __device__ __forceinline__ constexpr int chan_index(int j) { return QUADS ? 64 * (j >> 2) + (j & 3) : 16 * j; }
     static constexpr int S = 1 << (NLOG - 4);  // slice length per lane
     T R[S];                                    // level l (4 <= l < NLOG): 2^(l-4) values at offset 2^(l-4)
     // the first KEEP channel pairs of the lane's slice stay in registers between the top-level f and g, the rest
@@ -39,6 +43,22 @@ template <typename T, int NLOG, int KEEP = 0> struct RegDec {
     template <int LEV, bool IS_G> __device__ __forceinline__ void step(const T *chan_lane)
     {
         constexpr int c = 1 << (LEV - 5);
+        if constexpr (QUADS && LEV == NLOG && c >= 4 && sizeof(T) == 4) {
+            // four elements of the lane per 16-byte load
+#pragma unroll
+            for (int J = 0; J < c / 4; J++) {
+                const float4 a4 = *reinterpret_cast<const float4 *>(chan_lane + 64 * J);
+                const float4 b4 = *reinterpret_cast<const float4 *>(chan_lane + 64 * (J + c / 4));
+                const T a[4] = {a4.x, a4.y, a4.z, a4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int j = 4 * J + i;
+                    if constexpr (IS_G) R[c + j] = g_fast(a[i], b[i], (uint32_t)(ps0 >> (c + j)) & 1u);
+                    else R[c + j] = f_fast(a[i], b[i]);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < c; j++) {
             T a, b;
@@ -47,8 +67,8 @@ template <typename T, int NLOG, int KEEP = 0> struct RegDec {
                     a = CA[j];
                     b = CB[j];
                 } else {
-                    a = chan_lane[16 * j];
-                    b = chan_lane[16 * (j + c)];
+                    a = chan_lane[chan_index(j)];
+                    b = chan_lane[chan_index(j + c)];
                     if (!IS_G && j < KEEP) {
                         CA[j] = a;
                         CB[j] = b;
