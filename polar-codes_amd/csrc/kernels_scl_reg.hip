@@ -1,4 +1,4 @@
-// Register-resident list decoder, L = 8 paths, N = 64 .. 1024, fp32: one wavefront per frame, eight lanes
+// Register-resident list decoder, up to L = 8 paths (L = 2 and 4 leave positions empty), N = 64 .. 1024, fp32: one wavefront per frame, eight lanes
 // per path.
 //
 // Lane 8p + q belongs to list position p.  Inside a path, element k of every tree level lives in the lane
@@ -94,7 +94,7 @@ template <int NLOG> struct SclStore {
     static constexpr int GLOBAL_VALUES = NLOG == 10 ? 64 * 64 : 0;    // floats per wavefront
 };
 
-template <int NLOG> struct SclReg {
+template <int NLOG, int LMAX = 8> struct SclReg {
     static constexpr int S = SclStore<NLOG>::REG_VALUES;
     float R[S];           // level l (3 <= l < NLOG) kept in registers: 2^(l-3) values at offset 2^(l-3)
     float *lv_lds;        // the LDS level of this wavefront, + my lane
@@ -136,6 +136,7 @@ template <int NLOG> struct SclReg {
     uint64_t r0, r1;      // root (S bits)
     PathState st;
     int Lcur;
+    static constexpr int Lmax = LMAX;   // list size 2, 4 or 8: positions >= Lmax stay empty
 
     template <int C> static __device__ __forceinline__ uint64_t get_bits(uint64_t w0, uint64_t w1)
     {
@@ -255,28 +256,31 @@ template <int NLOG> struct SclReg {
         const float cpm = st.pm + branch_metric_fast(v, bme);
         int par;
         uint32_t b;
-        if (2 * Lcur <= 8) {
+        if (2 * Lcur <= Lmax) {
             const bool is_copy = lc.p >= Lcur && lc.p < 2 * Lcur;
             par = is_copy ? lc.p - Lcur : lc.p;
             b = is_copy ? 1u : 0u;
             Lcur *= 2;
         } else {
             // 16 candidates (p, u); my candidate is (lc.p, bme); my quad lane k compares it with 4 of the 16
-            const int cpos = bme ? lc.p : 8 + lc.p;  // copies (u=1) come first in the candidate order
+            // the candidates of empty positions (list sizes below 8) rank behind every real one
+            const bool alive = LMAX == 8 || lc.p < Lcur;
+            const float rpm = alive ? cpm : -INFINITY;
+            const int cpos = (bme ? lc.p : 8 + lc.p) + (alive ? 0 : 16);  // copies (u=1) come first in the candidate order
             const int k = lc.q & 3;
             int cnt = 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int op = 2 * k + (i >> 1), ob = i & 1;
-                const float opm = bperm_f(cpm, op * 8 + 4 * ob);
-                const int opos = ob ? op : 8 + op;
-                cnt += (opm > cpm || (opm == cpm && opos < cpos)) ? 1 : 0;
+                const float opm = bperm_f(rpm, op * 8 + 4 * ob);
+                const int opos = (ob ? op : 8 + op) + ((LMAX == 8 || op < Lcur) ? 0 : 16);
+                cnt += (opm > rpm || (opm == rpm && opos < cpos)) ? 1 : 0;
             }
             cnt += (int)dpp_mov_u32<0xB1>((uint32_t)cnt);
             cnt += (int)dpp_mov_u32<0x4E>((uint32_t)cnt);
-            if (k == 0 && cnt < 8) surv[cnt] = (uint32_t)(lc.p * 8 + 4 * (int)bme);
+            if (k == 0 && cnt < Lmax) surv[cnt] = (uint32_t)(lc.p * 8 + 4 * (int)bme);
             wave_sync();
-            const uint32_t s = surv[lc.p];
+            const uint32_t s = (LMAX == 8 || lc.p < Lmax) ? surv[lc.p] : (uint32_t)(lc.p * 8);
             wave_sync();
             par = (int)(s >> 3);
             b = (s >> 2) & 1u;
@@ -342,8 +346,8 @@ template <int NLOG> struct SclReg {
     }
 };
 
-template <int LEV, int NLOG>
-__device__ __forceinline__ void scl_node(SclReg<NLOG> &d, uint32_t maskv, const float *chan_lane, uint32_t idx, int plane,
+template <int LEV, int NLOG, int LMAX>
+__device__ __forceinline__ void scl_node(SclReg<NLOG, LMAX> &d, uint32_t maskv, const float *chan_lane, uint32_t idx, int plane,
                                          const LaneConst &lc, uint32_t *surv)
 {
 #pragma nounroll
@@ -359,16 +363,16 @@ __device__ __forceinline__ void scl_node(SclReg<NLOG> &d, uint32_t maskv, const 
                 d.b0 = (d.b0 & ~(uint64_t)2) | ((uint64_t)x << 1);
             } else {
                 d.a0 = (d.a0 & ~(uint64_t)2) | ((uint64_t)x << 1);
-                d.st.ownP = SclReg<NLOG>::own_set(d.st.ownP, 3, (uint32_t)lc.p);
+                d.st.ownP = SclReg<NLOG, LMAX>::own_set(d.st.ownP, 3, (uint32_t)lc.p);
             }
         } else {
-            scl_node<LEV - 1, NLOG>(d, maskv, chan_lane, cidx, (int)h, lc, surv);
+            scl_node<LEV - 1, NLOG, LMAX>(d, maskv, chan_lane, cidx, (int)h, lc, surv);
         }
     }
     d.template combine<LEV>(plane, lc);
 }
 
-template <int NLOG>
+template <int NLOG, int LMAX>
 __global__ void __launch_bounds__(64, NLOG == 10 ? 3 : 2) scl_reg_kernel(const float *__restrict__ llr, const uint32_t *__restrict__ maskw,
                                                         const uint16_t *__restrict__ Asl8, const uint32_t *__restrict__ crcS,
                                                         const uint32_t *__restrict__ truth, uint32_t *__restrict__ info_hat, int64_t B,
@@ -392,7 +396,7 @@ __global__ void __launch_bounds__(64, NLOG == 10 ? 3 : 2) scl_reg_kernel(const f
         lc.lowmask[i] = lc.up[i] ? 0u : 1u;
     }
     const uint32_t maskv = maskw[(lc.lane & 31) < (N / 32) ? (lc.lane & 31) : 0];
-    SclReg<NLOG> d;
+    SclReg<NLOG, LMAX> d;
     d.my_lane = lc.lane;
     d.lv_lds = lvl_s + lc.lane;
     d.lv_glb = slab + (size_t)blockIdx.x * SclStore<NLOG>::GLOBAL_VALUES + lc.lane;
@@ -405,7 +409,7 @@ __global__ void __launch_bounds__(64, NLOG == 10 ? 3 : 2) scl_reg_kernel(const f
 #pragma unroll
         for (int i = 0; i < 3; i++) d.st.v[i] = 0.0f;
         d.Lcur = 1;
-        scl_node<NLOG, NLOG>(d, maskv, chan_lane, 0u, 0, lc, surv);
+        scl_node<NLOG, NLOG, LMAX>(d, maskv, chan_lane, 0u, 0, lc, surv);
 
         // final stable descending order: rank of every position; the best path is rank 0
         const bool act = lc.p < d.Lcur;
@@ -497,18 +501,18 @@ __global__ void __launch_bounds__(64, NLOG == 10 ? 3 : 2) scl_reg_kernel(const f
 // ------------------------------------------------------------------------------------------ host side
 bool scl_reg_supported(const polar_code *c, int dtype, int L, const void *pm, const void *u_hat_all)
 {
-    if (dtype != POLAR_F32 || L != 8 || pm || u_hat_all) return false;
+    if (dtype != POLAR_F32 || (L != 8 && L != 4 && L != 2) || pm || u_hat_all) return false;
     if (c->n < 6 || c->n > 10 || c->K < 3) return false;
     const char *e = getenv("POLAR_SCL_KERNEL");
     if (e && e[0] == 'l') return false;  // "lds": force the LDS-staged kernel
     return true;
 }
 
-template <int NLOG>
+template <int NLOG, int LMAX>
 static int launch_scl_reg_t(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, bool crc, const uint32_t *truth)
 {
     polar_ctx *ctx = c->ctx;
-    auto kern = scl_reg_kernel<NLOG>;
+    auto kern = scl_reg_kernel<NLOG, LMAX>;
     // POLAR_SCL_LDSPAD (bytes of unused dynamic LDS per wavefront) lowers the occupancy for experiments
     const char *pe = getenv("POLAR_SCL_LDSPAD");
     const size_t pad = pe ? (size_t)atoi(pe) : 0;
@@ -526,7 +530,7 @@ static int launch_scl_reg_t(polar_code *c, const void *llr, uint32_t *info_hat, 
                        ctx->scl_slab.as<float>());
     HIP_TRY(hipGetLastError());
     float ms = tm.stop();
-    snprintf(c->last.kernel, sizeof(c->last.kernel), "scl_reg_kernel<%d>/L8", NLOG);
+    snprintf(c->last.kernel, sizeof(c->last.kernel), "scl_reg_kernel<%d>/L%d", NLOG, LMAX);
     c->last.lanes_per_frame = 64;
     c->last.lds_bytes_per_block = 32 + 1024 + 2 * c->N + 4 * SclStore<NLOG>::LDS_VALUES;
     c->last.block_threads = 64;
@@ -535,15 +539,25 @@ static int launch_scl_reg_t(polar_code *c, const void *llr, uint32_t *info_hat, 
     return POLAR_OK;
 }
 
-int launch_scl_reg(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, bool crc, const uint32_t *truth)
+template <int NLOG> static int launch_scl_reg_l(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, bool crc, const uint32_t *truth, int L)
+{
+    switch (L) {
+    case 8: return launch_scl_reg_t<NLOG, 8>(c, llr, info_hat, B, crc, truth);
+    case 4: return launch_scl_reg_t<NLOG, 4>(c, llr, info_hat, B, crc, truth);
+    case 2: return launch_scl_reg_t<NLOG, 2>(c, llr, info_hat, B, crc, truth);
+    default: polar_set_error("register SCL kernel: list size must be 2, 4 or 8"); return POLAR_EUNSUPPORTED;
+    }
+}
+
+int launch_scl_reg(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, bool crc, const uint32_t *truth, int L)
 {
     if (B == 0) return POLAR_OK;
     switch (c->n) {
-    case 6: return launch_scl_reg_t<6>(c, llr, info_hat, B, crc, truth);
-    case 7: return launch_scl_reg_t<7>(c, llr, info_hat, B, crc, truth);
-    case 8: return launch_scl_reg_t<8>(c, llr, info_hat, B, crc, truth);
-    case 9: return launch_scl_reg_t<9>(c, llr, info_hat, B, crc, truth);
-    case 10: return launch_scl_reg_t<10>(c, llr, info_hat, B, crc, truth);
+    case 6: return launch_scl_reg_l<6>(c, llr, info_hat, B, crc, truth, L);
+    case 7: return launch_scl_reg_l<7>(c, llr, info_hat, B, crc, truth, L);
+    case 8: return launch_scl_reg_l<8>(c, llr, info_hat, B, crc, truth, L);
+    case 9: return launch_scl_reg_l<9>(c, llr, info_hat, B, crc, truth, L);
+    case 10: return launch_scl_reg_l<10>(c, llr, info_hat, B, crc, truth, L);
     default: polar_set_error("register SCL kernel: unsupported length"); return POLAR_EUNSUPPORTED;
     }
 }

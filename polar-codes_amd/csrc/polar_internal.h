@@ -134,7 +134,7 @@ int launch_sc_big(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B)
 void sc_big_release(polar_code *c);
 bool scl_reg_supported(const polar_code *c, int dtype, int L, const void *pm, const void *u_hat_all);
 // truth (packed [B x Kw], or NULL): genie-aided choice of the output path
-int launch_scl_reg(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, bool crc, const uint32_t *truth);
+int launch_scl_reg(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, bool crc, const uint32_t *truth, int L);
 int launch_scl_decode(polar_code *c, const void *llr, int dtype, int L, uint32_t *info_hat, double *pm,
                       uint32_t *u_hat_all, int64_t B, bool crc, const uint32_t *truth);
 // nbits: leading bits of each K-bit word that are compared

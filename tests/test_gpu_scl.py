@@ -126,10 +126,12 @@ def test_scl_list_1_equals_sc_and_L_improves_fer():
     assert np.any(l8 != msg, axis=1).sum() <= np.any(sc != msg, axis=1).sum()
 
 
+@pytest.mark.parametrize("L", [8, 4, 2])
 @pytest.mark.parametrize("N,K", [(64, 32), (128, 64), (256, 128), (512, 256), (1024, 512), (1024, 300), (256, 200)])
-def test_scl_register_kernel_equals_lds_kernel(monkeypatch, N, K):
-    """The register-resident L=8 kernel and the LDS-staged kernel run the same fp32 arithmetic in the same
-    order (f, g, metric, candidate ranking): decoded bits must be identical, frame by frame."""
+def test_scl_register_kernel_equals_lds_kernel(monkeypatch, N, K, L):
+    """The register-resident kernel (list sizes 8, 4 and 2; the smaller ones leave list positions empty) and the
+    LDS-staged kernel run the same fp32 arithmetic in the same order (f, g, metric, candidate ranking): decoded bits
+    must be identical, frame by frame."""
     mask = pcf.degaBuild(N, K, 2.0)
     code = _native.Code(_native.default_ctx(), mask)
     rs = np.random.RandomState(N + K)
@@ -137,9 +139,9 @@ def test_scl_register_kernel_equals_lds_kernel(monkeypatch, N, K):
     x = oracle.polar_encode(rs.randint(0, 2, size=(B, K)), mask).reshape(B, N)
     n0 = 1.0 / (K / N * 10 ** (1.0 / 10))
     llr = code.channel_llr(x, n0, 11, 0, np.float32)  # Eb/N0 = 1 dB: plenty of close decisions
-    a, _, _ = code.scl_decode(llr, 8)
+    a, _, _ = code.scl_decode(llr, L)
     assert code.last_launch()["kernel"].startswith("scl_reg_kernel"), code.last_launch()
     monkeypatch.setenv("POLAR_SCL_KERNEL", "lds")
-    b, _, _ = code.scl_decode(llr, 8)
+    b, _, _ = code.scl_decode(llr, L)
     assert code.last_launch()["kernel"].startswith("scl_decode_kernel")
     assert np.array_equal(a, b), int(np.any(a != b, axis=1).sum())
