@@ -223,7 +223,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "Polar(1024,512) dega dSNR=2.0, SC decode, 1e7 frames per GPU, LLRs resident in HBM",
+            "config": {"workload": f"Polar(1024,512) dega dSNR=2.0, SC decode, {B:.0e} frames per GPU, LLRs resident in HBM".replace("e+0", "e"),
                        "frames_per_gpu": B, "snr_db": a.snr, "schedule": "fast (rate-0 / rate-1 subtrees short-cut)",
                        "parallelism": f"frames sharded over {world} GPU(s), counter all-reduce"},
             "frames_per_s": fps,
