@@ -82,19 +82,38 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary SCL / Monte-Carlo legs")
     a = ap.parse_args()
 
+    # N > 1 without a launcher: start the N ranks as fresh child processes (torch.distributed.run) before this
+    # process makes any GPU call, relay their output (rank 0 prints the JSON line) and leave with their exit code
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        import socket
+        import subprocess
+
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        raise SystemExit(subprocess.call(cmd, env=env))
+
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
     ndev = torch.cuda.device_count()
-    local = local % max(ndev, 1)  # rehearsals with more ranks than GPUs share devices (gloo only)
+    backend = os.environ.get("POLAR_BENCH_BACKEND", "nccl")  # "gloo" only to rehearse the multi-rank path with fewer GPUs than ranks
+    if world > ndev and backend == "nccl":
+        raise SystemExit(f"bench.py: {world} ranks but {ndev} GPU(s) visible; RCCL needs one GPU per rank "
+                         "(POLAR_BENCH_BACKEND=gloo rehearses the multi-rank path on shared GPUs)")
+    local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    backend = os.environ.get("POLAR_BENCH_BACKEND", "nccl")  # "gloo" only to rehearse the multi-rank path on one GPU
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -215,6 +234,8 @@ def main():
             "value": fps * K / 1e6,
             "unit": "Mb/s",
             "n_gpus": world,
+            "devices": min(world, ndev),
+            "collective": None if world == 1 else ("rccl" if backend == "nccl" else backend + " (rehearsal: ranks share GPUs)"),
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,

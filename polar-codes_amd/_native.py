@@ -360,11 +360,11 @@ def critical_set(mask, after=-1):
 
 
 def default_ctx(device=None):
-    """Process-wide context on `device` (default: LOCAL_RANK or 0)."""
+    """Process-wide context on `device` (default: POLAR_DEVICE, else LOCAL_RANK, else 0)."""
     global _default_ctx
     if _default_ctx is None:
         if device is None:
-            device = int(os.environ.get("LOCAL_RANK", "0"))
+            device = int(os.environ.get("POLAR_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         _default_ctx = Context(device)
     return _default_ctx
 

@@ -11,6 +11,7 @@ of ranks, because the generator is keyed by (seed, global frame index).
 """
 import os
 import time
+import warnings
 
 import numpy as np
 
@@ -66,6 +67,9 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+_warned_specialize = False
+
+
 def native_runner(pcode, decoder, L, dtype, crc=False, genie=False):
     """Default frame runner: polar_mc_run of the GPU library."""
     import _native
@@ -75,8 +79,12 @@ def native_runner(pcode, decoder, L, dtype, crc=False, genie=False):
             and 0 < pcode.infoLen < pcode.codewordLength:
         try:
             pcode.native.specialize()  # SC runs of a whole sweep repay the time the run-time compiler takes
-        except _native.PolarError:
-            pass  # without the run-time compiler the generic GPU kernel decodes the same bits
+        except _native.PolarError as e:  # without the run-time compiler the generic GPU kernel decodes the same bits
+            global _warned_specialize
+            if not _warned_specialize:
+                _warned_specialize = True
+                warnings.warn("run-time specialisation of the SC decoder failed (%s); the generic GPU kernel decodes the same "
+                              "bits at about half the rate" % e, RuntimeWarning)
     if crc:
         pcode._attach_crc()
     if decoder == "pbf":
@@ -130,7 +138,7 @@ def simulate(pcode, snrRange, frames=None, errCnt=100, minFrames=100000, maxFram
     if reduce_device is None:
         reduce_device = "cpu"
         if dist is not None and dist.get_backend() == "nccl":
-            reduce_device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
+            reduce_device = "cuda:%d" % int(os.environ.get("POLAR_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     result = BERFER()
     for ip, snr in enumerate(snrRange):
         snr = float(snr)

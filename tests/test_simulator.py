@@ -99,3 +99,119 @@ def test_two_rank_gloo_job_gives_single_rank_totals(tmp_path):
     assert r0[0] == single.frames and r0[1] == single.frameErrors and r0[2] == single.bitErrors
     # stop-rule mode: both ranks ran the same number of rounds; totals are multiples of world*batch
     assert r0[3][0] % 200 == 0 and r0[3][0] >= 300 and r0[4][0] >= 40
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`bench.py --gpus 2` without a launcher starts two ranks itself, before any GPU call of its own; without a GPU every
+    rank stops with the same message and the exit code is passed on."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("CPU-side check of the launcher (the GPU run is test_bench_two_rank_rehearsal)")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu",
+                          "--no-extras"], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode != 0
+    assert out.stderr.count("bench.py needs a GPU") == 2, out.stderr[-2000:]
+
+
+# ---- GPU: the real frame runner (polar_mc_run) under torch.distributed ----------------------------------------------
+NATIVE_WORKER = r'''
+import os, sys, json
+sys.path[:0] = [%(root)r, %(root)r + "/polar-codes_amd"]
+import numpy as np
+import torch
+import torch.distributed as dist
+os.environ["POLAR_DEVICE"] = "0"          # every rank of this rehearsal shares GPU 0
+backend = %(backend)r
+if backend == "nccl":
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+else:
+    dist.init_process_group("gloo")
+import simulator
+from polarCode import PolarCode
+out = {}
+for name, N, K, dec, L, frames in (("sc", 1024, 512, "sc", 1, 20001), ("scl", 256, 128, "scl", 4, 3001)):
+    pc = PolarCode(N, K, "dega", 2.0, listSize=L)
+    pc.decoderType, pc.snrType, pc.modu = dec, "SNRb", "BPSK"
+    res = simulator.simulate(pc, [1.0, 2.0], frames=frames, batch=4096, seed=7, verbose=False)
+    out[name] = [res.frames, res.frameErrors, res.bitErrors, pc.native.last_launch()["kernel"]]
+pc = PolarCode(128, 64, "dega", 2.0)
+pc.decoderType, pc.snrType, pc.modu = "sc", "SNRb", "BPSK"
+stop = simulator.simulate(pc, [1.0], frames=None, errCnt=50, minFrames=3000, batch=1000, seed=3, verbose=False)
+out["stop"] = [stop.frames, stop.frameErrors]
+out["backend"] = dist.get_backend()
+open(os.path.join(%(out)r, "rank%%d.json" %% dist.get_rank()), "w").write(json.dumps(out))
+dist.destroy_process_group()
+'''
+
+
+def _run_native_job(tmp_path, nproc, backend, port):
+    import json
+
+    script = tmp_path / "native_worker.py"
+    script.write_text(NATIVE_WORKER % {"root": ROOT, "out": str(tmp_path), "backend": backend})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nproc, "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), str(script)], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return [json.loads((tmp_path / ("rank%d.json" % r)).read_text()) for r in range(nproc)]
+
+
+def _single_process_totals():
+    from polarCode import PolarCode
+
+    out = {}
+    for name, N, K, dec, L, frames in (("sc", 1024, 512, "sc", 1, 20001), ("scl", 256, 128, "scl", 4, 3001)):
+        pc = PolarCode(N, K, "dega", 2.0, listSize=L)
+        pc.decoderType, pc.snrType, pc.modu = dec, "SNRb", "BPSK"
+        res = simulator.simulate(pc, [1.0, 2.0], frames=frames, batch=frames, seed=7, verbose=False)
+        out[name] = [res.frames, res.frameErrors, res.bitErrors]
+    return out
+
+
+@pytest.mark.gpu
+def test_rccl_one_rank_job_runs_the_device_all_reduce(tmp_path):
+    """A fresh process initialises RCCL (backend "nccl", world size 1) and runs simulate() with the GPU library as the
+    frame runner: the counters go through a device-tensor all-reduce and equal the run without torch.distributed."""
+    (r0,) = _run_native_job(tmp_path, 1, "nccl", 29541)
+    assert r0["backend"] == "nccl"
+    single = _single_process_totals()
+    for name in ("sc", "scl"):
+        assert r0[name][:3] == single[name], name
+    assert r0["sc"][3].startswith("sc_static_mc_kernel")
+
+
+@pytest.mark.gpu
+def test_two_rank_job_with_the_gpu_frame_runner(tmp_path):
+    """Two ranks (both on GPU 0, counters reduced over gloo) shard the frame range and run polar_mc_run on their shares:
+    the totals equal the single-process run, whatever the split and the batch size."""
+    r0, r1 = _run_native_job(tmp_path, 2, "gloo", 29543)
+    assert r0 == r1
+    single = _single_process_totals()
+    for name in ("sc", "scl"):
+        assert r0[name][:3] == single[name], name
+    assert r0["stop"][0][0] % 2000 == 0 and r0["stop"][0][0] >= 3000 and r0["stop"][1][0] >= 50
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal():
+    """bench.py --gpus 2 starts its two ranks itself; on a one-GPU box they share the GPU and reduce over gloo."""
+    import json
+
+    import torch
+
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    if torch.cuda.device_count() < 2:
+        env["POLAR_BENCH_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames",
+                          "200000", "--no-cpu", "--no-extras"], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["counters"][0] == 400000 and line["value"] > 0

@@ -302,8 +302,8 @@ def gen_curves(functions, polarCode, channel):
     nproc = int(os.environ.get("GOLDEN_PROCS", "6"))
     plan = [
         ("sc_128_64", 128, 64, "dega", 2.0, "sc", 0, [1.0, 1.5, 2.0, 2.5, 3.0], 25000),
-        ("sc_1024_512", 1024, 512, "dega", 2.0, "sc", 0, [1.0, 1.5, 2.0, 2.5, 3.0], 6000),
-        ("scl8_1024_512", 1024, 512, "dega", 2.0, "scl", 8, [1.0, 1.5, 2.0, 2.5], 1200),
+        ("sc_1024_512", 1024, 512, "dega", 2.0, "sc", 0, [1.0, 1.5, 2.0, 2.5, 3.0], 20000),
+        ("scl8_1024_512", 1024, 512, "dega", 2.0, "scl", 8, [1.0, 1.5, 2.0, 2.5], 5000),
         ("scl4_128_64", 128, 64, "dega", 2.0, "scl", 4, [1.0, 2.0, 3.0], 6000),
     ]
     out = {}
@@ -322,7 +322,7 @@ def gen_curves(functions, polarCode, channel):
                 rows.append((snr, fr, fe, be, be2))  # be2 = sum of squared per-frame bit errors
                 print(f"curve {tag} {snr} dB: frames {fr} fe {fe} be {be} ({time.time()-t0:.0f}s)", flush=True)
             out[tag] = np.array(rows, dtype=np.float64)
-            np.savez_compressed(os.path.join(OUT, "curves.npz"), **out)
+            np.savez_compressed(os.environ.get("GOLDEN_CURVES_OUT", os.path.join(OUT, "curves.npz")), **out)
 
 
 # --------------------------------------------------------------------------- main.py flow (bit-reversed variant)
