@@ -176,6 +176,16 @@ int polar_pbf_decode(polar_code *code, const void *llr, int dtype, int max_level
 int polar_pbf_decode_packed(polar_code *code, const void *llr, int dtype, int max_level, uint32_t *info_hat,
                             int32_t *runs, uint8_t *crc_ok, int32_t *last_seq, int64_t B, int space);
 
+/* polar_pbf_decode_packed on device buffers (POLAR_DEVICE) for callers that cannot allocate device memory: code running
+ * under HIP graph capture, serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  The call makes
+ * no hipMalloc / hipFree: the list of frames whose first SC run fails the CRC and the two counters of the search live in a
+ * file-scope device array of 4 MiB + 256 B that each GPU the library runs on holds until the process ends.
+ * Limits: B <= 2^20 frames per call (more is rejected with POLAR_EINVAL), N <= 1024; polar_code_set_crc and (for
+ * max_level >= 1) polar_code_set_reliability must have been called: they build every table the search needs.
+ * All calls on one GPU share that array: calls that overlap on one GPU (two streams, two contexts) race. */
+int polar_pbf_decode_noalloc(polar_code *code, const void *llr, int dtype, int max_level, uint32_t *info_hat, int32_t *runs,
+                             uint8_t *crc_ok, int32_t *last_seq, int64_t B);
+
 /* ---- error counting: pcf.fails per frame (cn/functions.py:107-109) plus the fer/ber counters of the
  *      driver loop (cn/simulator.py:216-226).  Adds to counters[0..2] = frames, frame errors, bit errors
  *      (device uint64[3]).  Packed device buffers.  With POLAR_CRC only the K - width message bits count. */

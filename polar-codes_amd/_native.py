@@ -67,6 +67,7 @@ SIGNATURES = {
     "polar_sc_decode_flip": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _i]),
     "polar_pbf_decode": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _i]),
     "polar_pbf_decode_packed": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _i]),
+    "polar_pbf_decode_noalloc": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i64]),
     "polar_sc_decode_count": (_i, [_vp, _vp, _i, _vp, _vp, _i64, _i, _vp]),
     "polar_count_errors": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "polar_mc_run": (_i, [_vp, _i, _i, _i, _i, _d, _u64, _u64, _i64, _vp]),
@@ -295,6 +296,10 @@ class Code:
     def pbf_decode_dev(self, llr_ptr, dtype, max_level, info_hat_ptr, B, runs_ptr=None, ok_ptr=None, last_ptr=None):
         _check(lib().polar_pbf_decode_packed(self._h, llr_ptr, _dt(dtype), int(max_level), info_hat_ptr, runs_ptr, ok_ptr, last_ptr,
                                              B, DEVICE))
+
+    def pbf_decode_noalloc_dev(self, llr_ptr, dtype, max_level, info_hat_ptr, B, runs_ptr=None, ok_ptr=None, last_ptr=None):
+        """pbf_decode_dev for callers that cannot allocate: at most 2^20 frames per call, N <= 1024."""
+        _check(lib().polar_pbf_decode_noalloc(self._h, llr_ptr, _dt(dtype), int(max_level), info_hat_ptr, runs_ptr, ok_ptr, last_ptr, B))
 
     def mc_run(self, decoder, L, dtype, N0, seed, frame0, nframes, fast=True, crc=False, genie=False):
         cnt = np.zeros(3, dtype=np.uint64)

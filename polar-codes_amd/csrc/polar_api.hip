@@ -5,11 +5,15 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <new>
 
 #include "polar_internal.h"
 
 static thread_local char g_err[512] = "";
+
+int polar_noalloc_setup(int device);
+static int ensure_flip_tables(polar_code *c, bool need_lists);
 
 void polar_set_error(const char *fmt, ...)
 {
@@ -55,6 +59,10 @@ extern "C" int polar_ctx_create(int device, polar_ctx **out)
         return POLAR_EINVAL;
     }
     HIP_TRY(hipSetDevice(device));
+    {
+        int rc = polar_noalloc_setup(device);
+        if (rc) return rc;
+    }
     polar_ctx *c = new (std::nothrow) polar_ctx();
     if (!c) return POLAR_ENOMEM;
     c->device = device;
@@ -653,7 +661,8 @@ extern "C" int polar_code_set_reliability(polar_code *c, const double *mu)
     if (!c->d_sqrt_mu) HIP_TRY(hipMalloc((void **)&c->d_sqrt_mu, sizeof(double) * c->N));
     HIP_TRY(hipMemcpy(c->d_sqrt_mu, s.data(), sizeof(double) * c->N, hipMemcpyHostToDevice));
     c->have_mu = true;
-    return POLAR_OK;
+    // the candidate tables of the flip search depend on the rate profile only; built here so that no decode call has to
+    return ensure_flip_tables(c, true);
 }
 
 // Candidate tables of the flip search; the per-position lists are only needed from two simultaneous flips on.
@@ -689,6 +698,20 @@ static int ensure_flip_tables(polar_code *c, bool need_lists)
 
 // Device-side body: fast SC on every frame, CRC test, search kernel on the frames that failed.
 // wi: packed information words out; d_runs / d_ok / d_last: device side outputs or NULL.
+// rows (one word per frame) and ctr (two 64-bit words: work counter, row count) are the scratch of the call.
+static int pbf_device_on(polar_code *c, const void *dl, int dtype, int max_level, uint32_t *wi, int32_t *d_runs, uint8_t *d_ok,
+                         int32_t *d_last, int64_t nb, uint32_t *rows, unsigned long long *ctr)
+{
+    polar_ctx *ctx = c->ctx;
+    int rc;
+    HIP_TRY(hipMemsetAsync(ctr, 0, 16, ctx->stream));
+    if ((rc = launch_sc_decode(c, dl, dtype, wi, nullptr, nullptr, nb, POLAR_SC_FAST))) return rc;
+    if ((rc = launch_crc_filter(c, wi, rows, ctr + 1, d_runs, d_ok, d_last, nb))) return rc;
+    if (max_level >= 1)
+        rc = launch_pbf(c, dl, dtype, rows, ctr + 1, ctr, nullptr, max_level, true, wi, nullptr, nullptr, d_runs, d_ok, d_last, nb);
+    return rc;
+}
+
 static int pbf_device(polar_code *c, const void *dl, int dtype, int max_level, uint32_t *wi, int32_t *d_runs, uint8_t *d_ok,
                       int32_t *d_last, int64_t nb)
 {
@@ -696,14 +719,8 @@ static int pbf_device(polar_code *c, const void *dl, int dtype, int max_level, u
     int rc;
     if ((rc = ensure_flip_tables(c, max_level >= 2))) return rc;
     if ((rc = ctx->flip_rows.reserve(nb * 4)) || (rc = ctx->flip_ctr.reserve(16))) return rc;
-    unsigned long long *ctr = ctx->flip_ctr.as<unsigned long long>();
-    HIP_TRY(hipMemsetAsync(ctr, 0, 16, ctx->stream));
-    if ((rc = launch_sc_decode(c, dl, dtype, wi, nullptr, nullptr, nb, POLAR_SC_FAST))) return rc;
-    if ((rc = launch_crc_filter(c, wi, ctx->flip_rows.as<uint32_t>(), ctr + 1, d_runs, d_ok, d_last, nb))) return rc;
-    if (max_level >= 1)
-        rc = launch_pbf(c, dl, dtype, ctx->flip_rows.as<uint32_t>(), ctr + 1, ctr, nullptr, max_level, true, wi, nullptr, nullptr,
-                        d_runs, d_ok, d_last, nb);
-    return rc;
+    return pbf_device_on(c, dl, dtype, max_level, wi, d_runs, d_ok, d_last, nb, ctx->flip_rows.as<uint32_t>(),
+                         ctx->flip_ctr.as<unsigned long long>());
 }
 
 static int pbf_common(polar_code *c, const void *llr, int dtype, int max_level, void *info_hat, int32_t *runs, uint8_t *crc_ok,
@@ -769,6 +786,61 @@ extern "C" int polar_pbf_decode_packed(polar_code *c, const void *llr, int dtype
                                        int32_t *runs, uint8_t *crc_ok, int32_t *last_seq, int64_t B, int space)
 {
     return pbf_common(c, llr, dtype, max_level, info_hat, runs, crc_ok, last_seq, B, space, true);
+}
+
+// ---- the same search for callers that cannot allocate (HIP graph capture, serving loops): the list of frames that
+// failed their CRC and the two counters of the search live in a file-scope device array instead of the context's
+// grow-only buffers.  Every GPU holds its own copy of the array at its own address: that address is looked up once per
+// device, with the device current, when the first context on it is created, and only the looked-up pointer is ever
+// handed to a kernel or a memset (the array's name in host code is not a device address).
+static const int64_t PBF_NOALLOC_MAX_FRAMES = (int64_t)1 << 20;
+static __device__ __align__(256) unsigned char pbf_scratch[256 + 4 * ((size_t)1 << 20)];  // counters, then one row word per frame
+static const int MAX_DEVICES = 64;
+static void *g_pbf_scratch[MAX_DEVICES];
+static std::mutex g_pbf_scratch_mu;
+
+int polar_noalloc_setup(int device)
+{
+    if (device < 0 || device >= MAX_DEVICES) return POLAR_OK;  // such a device has no scratch; the entry point says so
+    std::lock_guard<std::mutex> lk(g_pbf_scratch_mu);
+    if (g_pbf_scratch[device]) return POLAR_OK;
+    void *ptr = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(pbf_scratch)));
+    g_pbf_scratch[device] = ptr;
+    return POLAR_OK;
+}
+
+extern "C" int polar_pbf_decode_noalloc(polar_code *c, const void *llr, int dtype, int max_level, uint32_t *info_hat, int32_t *runs,
+                                        uint8_t *crc_ok, int32_t *last_seq, int64_t B)
+{
+    CHECK_COMMON(c, B, POLAR_DEVICE);
+    ARG_TRY(llr && info_hat, "NULL buffer");
+    ARG_TRY(dtype == POLAR_F32 || dtype == POLAR_F64, "dtype must be POLAR_F32 or POLAR_F64");
+    ARG_TRY(max_level >= 0 && max_level <= 3, "max_level must be in [0, 3]");
+    ARG_TRY(c->crc_w > 0, "bit flipping needs polar_code_set_crc first");
+    ARG_TRY(max_level == 0 || c->have_mu, "bit flipping needs polar_code_set_reliability first");
+    if (B > PBF_NOALLOC_MAX_FRAMES) {
+        polar_set_error("polar_pbf_decode_noalloc: %lld frames exceed the scratch array's capacity of %lld frames per call",
+                        (long long)B, (long long)PBF_NOALLOC_MAX_FRAMES);
+        return POLAR_EINVAL;
+    }
+    if (c->n > 10) {
+        polar_set_error("polar_pbf_decode_noalloc: N=%d; codes longer than 1024 are decoded with library-allocated workspace", c->N);
+        return POLAR_EUNSUPPORTED;
+    }
+    if (max_level >= 1 && (!c->d_S0 || (max_level >= 2 && !c->have_crit))) {
+        polar_set_error("polar_pbf_decode_noalloc: candidate tables missing (polar_code_set_reliability builds them)");
+        return POLAR_EINVAL;
+    }
+    const int dev = c->ctx->device;
+    unsigned char *scr = dev < MAX_DEVICES ? (unsigned char *)g_pbf_scratch[dev] : nullptr;
+    if (!scr) {
+        polar_set_error("polar_pbf_decode_noalloc: no scratch array on device %d", dev);
+        return POLAR_EUNSUPPORTED;
+    }
+    // the counters are cleared by pbf_device_on; the row list needs no clearing (only rows[0 .. row count) are read)
+    return pbf_device_on(c, llr, dtype, max_level, info_hat, runs, crc_ok, last_seq, B, reinterpret_cast<uint32_t *>(scr + 256),
+                         reinterpret_cast<unsigned long long *>(scr));
 }
 
 extern "C" int polar_sc_decode_flip(polar_code *c, const void *llr, int dtype, const int32_t *flips, uint8_t *info_hat,
