@@ -17,6 +17,9 @@
  *   - calls are stream-ordered on the context's stream and synchronous at the ABI for POLAR_HOST;
  *     for POLAR_DEVICE they return after enqueueing (use polar_ctx_sync or your own stream sync).
  *   - a context and the codes made from it belong to one host thread and one GPU.
+ *   - code lengths: N is a power of two, 2 <= N <= 65536, for the encoder, the channel and fp32 SC decoding; fp64 SC decoding
+ *     stops at N = 32768 (a frame's tree must fit a wavefront's LDS; POLAR_EUNSUPPORTED beyond); the list, genie and flip decoders take N <= 4096
+ *     (POLAR_EUNSUPPORTED beyond, checked before anything is launched).
  */
 #ifndef POLAR_HIP_H
 #define POLAR_HIP_H

@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpolar_hip.so")
+LIB_PATH = os.environ.get("POLAR_HIP_LIB") or os.path.join(_HERE, "libpolar_hip.so")  # POLAR_HIP_LIB: an instrumented build
 
 HOST, DEVICE = 0, 1
 F32, F64 = 0, 1

@@ -21,6 +21,7 @@
 // throughput mode (statistical parity); fp64 parity runs on the LDS-staged kernel.
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 
@@ -75,10 +76,41 @@ struct PathState {
 
 constexpr int XB = 24;
 
+// -DPOLAR_SCL_PROFILE: per-category wall-clock cycles of the register list decoder, summed over wavefronts
+// (development aid; scripts/gpu_scl_prof.sh builds a second library with it)
+#ifdef POLAR_SCL_PROFILE
+__device__ unsigned long long g_scl_prof[64];
+#define PROF_DECL unsigned long long prof_t = __builtin_readcyclecounter(), prof_acc[24] = {}
+#define PROF_ADD(cat)                                              \
+    do {                                                           \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        prof_acc[cat] += now_ - prof_t;                            \
+        prof_t = now_;                                             \
+    } while (0)
+#define PROF_ARGS , unsigned long long &prof_t, unsigned long long *prof_acc
+#define PROF_PASS , prof_t, prof_acc
+#define PROF_COUNT(cat)                                                    \
+    do {                                                                   \
+        if (lc.lane == 0) atomicAdd(&g_scl_prof[cat], 1ull);               \
+    } while (0)
+#else
+#define PROF_COUNT(cat)
+#define PROF_DECL
+#define PROF_ADD(cat)
+#define PROF_ARGS
+#define PROF_PASS
+#endif
+
 struct LaneConst {
     int lane, p, q, e;
     bool up[3];          // P = 8, 4, 2: my element is in the upper half
     uint32_t lowmask[3];
+    // ranking of the 16 candidates of a saturated list: my candidate is (p, u = q >> 2); quad lane k = q & 3 compares
+    // it with candidates (2k, 0), (2k, 1), (2k+1, 0), (2k+1, 1)
+    int rsrc[4];         // byte address (lane * 4) of a lane that holds the other candidate's metric
+    uint32_t rsub[4];    // 1 if the other candidate precedes mine in the candidate order copies(u=1) ++ originals(u=0)
+    uint32_t keepflip;   // 1 for the lanes that evaluate u = 0
+    uint32_t ubit[2];    // bit 31 = the u of my own / of my path's other candidate
 };
 
 // At N = 1024 a path's slice is 128 LLRs per lane; with all of them in registers two wavefronts fit on a SIMD, and the
@@ -158,21 +190,30 @@ template <int NLOG, int LMAX = 8> struct SclReg {
         return (row & ~(7u << (3 * (lev - 3)))) | (p << (3 * (lev - 3)));
     }
 
+    // Both steps read their operands in batches of up to 16 pairs before the first result of the batch is stored: loads
+    // that follow a store to memory the compiler cannot tell apart would otherwise wait for it one by one (64 dependent
+    // round trips at the top level instead of 4).
     // f: level LEV -> LEV-1 from my own values (or the channel at the top)
     template <int LEV> __device__ __forceinline__ void step_f(const float *chan_lane, const LaneConst &lc)
     {
         constexpr int c = 1 << (LEV - 4);
+        constexpr bool MEM = LEV == NLOG || LEV == SclStore<NLOG>::GLOBAL_LEVEL || LEV == SclStore<NLOG>::LDS_LEVEL;
+        constexpr int BT = !MEM ? 1 : c < 16 ? c : 16;
 #pragma unroll
-        for (int j = 0; j < c; j++) {
-            float a, b;
-            if constexpr (LEV == NLOG) {
-                a = chan_lane[8 * j];
-                b = chan_lane[8 * (j + c)];
-            } else {
-                a = ld_own<LEV>(j);
-                b = ld_own<LEV>(c + j);
+        for (int j0 = 0; j0 < c; j0 += BT) {
+            float a[BT], b[BT];
+#pragma unroll
+            for (int t = 0; t < BT; t++) {
+                if constexpr (LEV == NLOG) {
+                    a[t] = chan_lane[8 * (j0 + t)];
+                    b[t] = chan_lane[8 * (j0 + t + c)];
+                } else {
+                    a[t] = ld_own<LEV>(j0 + t);
+                    b[t] = ld_own<LEV>(c + j0 + t);
+                }
             }
-            st_own<LEV - 1>(j, f_fast(a, b));
+#pragma unroll
+            for (int t = 0; t < BT; t++) st_own<LEV - 1>(j0 + t, f_fast(a[t], b[t]));
         }
         level_written<LEV - 1>();
         st.ownL = own_set(st.ownL, LEV - 1, (uint32_t)lc.p);
@@ -181,24 +222,30 @@ template <int NLOG, int LMAX = 8> struct SclReg {
     template <int LEV> __device__ __forceinline__ void step_g(const float *chan_lane, const LaneConst &lc)
     {
         constexpr int c = 1 << (LEV - 4);
+        constexpr bool MEM = LEV == NLOG || LEV == SclStore<NLOG>::GLOBAL_LEVEL || LEV == SclStore<NLOG>::LDS_LEVEL;
+        constexpr int BT = MEM ? (c < 16 ? c : 16) : (c < 4 ? c : 4);  // register levels: four pairs of lane gathers in flight
         const int srcP = (int)own_get(st.ownP, LEV - 1) * 8 + lc.q;
+        const int srcL = (LEV == NLOG) ? 0 : (int)own_get(st.ownL, LEV) * 8 + lc.q;
         uint64_t bits;
         if constexpr (c == 64) bits = bperm_u64(a1, srcP);
         else if constexpr (c >= 16) bits = (bperm_u64(a0, srcP) >> c) & (((uint64_t)1 << c) - 1);
         else bits = (uint64_t)((bperm_u((uint32_t)a0, srcP) >> c) & ((1u << c) - 1u));
-        const int srcL = (LEV == NLOG) ? 0 : (int)own_get(st.ownL, LEV) * 8 + lc.q;
         // operands are level LEV, results level LEV-1: no lane overwrites what another still reads
 #pragma unroll
-        for (int j = 0; j < c; j++) {
-            float a, b;
-            if constexpr (LEV == NLOG) {
-                a = chan_lane[8 * j];
-                b = chan_lane[8 * (j + c)];
-            } else {
-                a = ld_from<LEV>(j, srcL);
-                b = ld_from<LEV>(c + j, srcL);
+        for (int j0 = 0; j0 < c; j0 += BT) {
+            float a[BT], b[BT];
+#pragma unroll
+            for (int t = 0; t < BT; t++) {
+                if constexpr (LEV == NLOG) {
+                    a[t] = chan_lane[8 * (j0 + t)];
+                    b[t] = chan_lane[8 * (j0 + t + c)];
+                } else {
+                    a[t] = ld_from<LEV>(j0 + t, srcL);
+                    b[t] = ld_from<LEV>(c + j0 + t, srcL);
+                }
             }
-            st_own<LEV - 1>(j, g_fast(a, b, (uint32_t)(bits >> j) & 1u));
+#pragma unroll
+            for (int t = 0; t < BT; t++) st_own<LEV - 1>(j0 + t, g_fast(a[t], b[t], (uint32_t)(bits >> (j0 + t)) & 1u));
         }
         level_written<LEV - 1>();
         st.ownL = own_set(st.ownL, LEV - 1, (uint32_t)lc.p);
@@ -289,6 +336,74 @@ template <int NLOG, int LMAX = 8> struct SclReg {
         return b;
     }
 
+    // The same leaf once the list is full (every later information bit prunes 2 Lmax candidates to Lmax), as
+    // straight-line code with as few dependent trips through the LDS crossbar as the data flow allows:
+    //  1. the four metrics a lane ranks its candidate against arrive together;
+    //  2. when every path's better candidate keeps the path's own list position (the common case at reliable bits)
+    //     nothing moves between lane groups: a wave-uniform test on the ranks ends the leaf there;
+    //  3. otherwise every lane writes its per-path state, once per surviving child, into the record of the child's new
+    //     position (xch[word][position * 8 + q]) and reads the record of its own position back: one write and one read
+    //     instead of a survivor table followed by gathers from the parent's lanes.
+    template <uint32_t LIVE> __device__ __forceinline__ uint32_t leaf_sat(float v, const LaneConst &lc, uint32_t *xch)
+    {
+        const uint32_t bme = (uint32_t)lc.q >> 2;
+        const float cpm = st.pm + branch_metric_fast(v, bme);
+        const bool alive = LMAX == 8 || lc.p < LMAX;
+        const float rpm = alive ? cpm : -INFINITY;
+        // ranks on integer keys with the order of the metrics (no NaN and no -0 occurs): "the other candidate wins" =
+        // its key is larger, or equal while it comes first in the candidate order, i.e. key_other > key_mine - before
+        const uint32_t rx = __float_as_uint(rpm);
+        const uint32_t key = rx ^ ((uint32_t)((int32_t)rx >> 31) | 0x80000000u);
+        uint32_t o[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(lc.rsrc[i], (int)key);
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) cnt += (o[i] > key - lc.rsub[i]) ? 1 : 0;
+        cnt += (int)dpp_mov_u32<0xB1>((uint32_t)cnt);
+        cnt += (int)dpp_mov_u32<0x4E>((uint32_t)cnt);
+        const bool keep = cnt == lc.p;
+        constexpr uint64_t EVERY = LMAX == 8 ? 0x0101010101010101ull : LMAX == 4 ? 0x01010101ull : 0x0101ull;
+        const uint64_t km = __ballot(keep);
+        const float cpm_o = dpp_mov<0x141>(cpm);  // the metric of my path's other candidate
+        PROF_COUNT(22);
+        if (((km | (km >> 4)) & EVERY) == EVERY) {
+            PROF_COUNT(23);
+            st.pm = keep ? cpm : cpm_o;
+            return (keep ? 1u : 0u) ^ lc.keepflip;  // u = 1 survived iff the u = 1 lanes keep / the u = 0 lanes do not
+        }
+        const int cnt_o = (int)dpp_mov_u32<0x141>((uint32_t)cnt);  // the rank of my path's other candidate
+        const int rk[2] = {cnt, cnt_o};
+        const float mt[2] = {cpm, cpm_o};
+#pragma unroll
+        for (int u = 0; u < 2; u++) {  // my own candidate, then my path's other one
+            if (rk[u] < Lmax) {
+                uint32_t *rec = xch + rk[u] * 8 + lc.q;
+                rec[0] = __float_as_uint(mt[u]);
+                rec[64] = st.ownL;
+                rec[128] = st.ownP | lc.ubit[u];
+                int w = 3;
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+                    if ((LIVE >> i) & 1u) rec[64 * w++] = __float_as_uint(st.v[i]);
+            }
+        }
+        wave_sync();
+        const uint32_t *mine = xch + lc.lane;
+        st.pm = __uint_as_float(mine[0]);
+        st.ownL = mine[64];
+        const uint32_t op = mine[128];
+        {
+            int w = 3;
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+                if ((LIVE >> i) & 1u) st.v[i] = __uint_as_float(mine[64 * w++]);
+        }
+        wave_sync();
+        st.ownP = op & 0x7FFFFFFFu;
+        return op >> 31;
+    }
+
     // A node of P leaves (2, 4 or 8), all frozen: nothing forks and every partial sum is zero, so the P decision LLRs
     // are computed side by side (after the exchange for period Q the lanes of the lower half hold the left child's
     // element, the others the right child's: lane element e ends with the LLR of leaf e mod P), the P metric
@@ -344,21 +459,79 @@ template <int NLOG, int LMAX = 8> struct SclReg {
             return xr ^ (xl_now & lc.lowmask[I]);
         }
     }
+
+    // The same node with its rate profile known at compile time and the list full: no branch on the profile is left,
+    // an all-frozen left half skips the save / restore of the node's LLR (nothing forks inside it).
+    template <int P, uint32_t MASK, uint32_t LIVE = 0u>
+    __device__ __forceinline__ uint32_t sub_s(float v, const LaneConst &lc, uint32_t *surv)
+    {
+        if constexpr (MASK == 0u) {
+            if constexpr (P == 1) st.pm += branch_metric_fast(v, 0u);
+            else frozen_node<P>(v, lc);
+            return 0u;
+        } else if constexpr (P == 1) {
+            return leaf_sat<LIVE>(v, lc, surv);
+        } else {
+            constexpr int I = P == 8 ? 0 : P == 4 ? 1 : 2;
+            constexpr uint32_t HALF = (1u << (P / 2)) - 1u;
+            constexpr uint32_t ML = MASK & HALF, MR = (MASK >> (P / 2)) & HALF;
+            const float o = partner8<P>(v);
+            const float vl = f_fast(v, o);
+            if constexpr (ML == 0u) {
+                if constexpr (P == 2) st.pm += branch_metric_fast(vl, 0u);
+                else frozen_node<P / 2>(vl, lc);
+                return sub_s<P / 2, MR, LIVE>(v + o, lc, surv);
+            } else {
+                st.v[I] = v;
+                const uint32_t xl = sub_s<P / 2, ML, LIVE | (1u << I)>(vl, lc, surv);
+                st.ownL = (st.ownL & ~(1u << (XB + I))) | (xl << (XB + I));
+                const float t = flip_sign(st.v[I], xl & lc.lowmask[I]);
+                const float vr = t + partner8<P>(t);
+                const uint32_t xr = sub_s<P / 2, MR, LIVE>(vr, lc, surv);
+                const uint32_t xl_now = (st.ownL >> (XB + I)) & 1u;
+                return xr ^ (xl_now & lc.lowmask[I]);
+            }
+        }
+    }
+
+    // An 8-leaf node: the nine rate profiles a code built from a reliability order can have here (beside all-frozen)
+    // run as compiled straight-line code once the list is full, anything else through the generic form.
+    __device__ __forceinline__ uint32_t node8(float v, uint32_t m8, const LaneConst &lc, uint32_t *surv)
+    {
+        if (__builtin_amdgcn_readfirstlane(Lcur) == Lmax) {
+            switch (m8) {
+            case 0x00u: frozen_node<8>(v, lc); return 0u;
+            case 0x80u: return sub_s<8, 0x80u>(v, lc, surv);
+            case 0xC0u: return sub_s<8, 0xC0u>(v, lc, surv);
+            case 0xE0u: return sub_s<8, 0xE0u>(v, lc, surv);
+            case 0xE8u: return sub_s<8, 0xE8u>(v, lc, surv);
+            case 0xF0u: return sub_s<8, 0xF0u>(v, lc, surv);
+            case 0xF8u: return sub_s<8, 0xF8u>(v, lc, surv);
+            case 0xFCu: return sub_s<8, 0xFCu>(v, lc, surv);
+            case 0xFEu: return sub_s<8, 0xFEu>(v, lc, surv);
+            case 0xFFu: return sub_s<8, 0xFFu>(v, lc, surv);
+            default: break;
+            }
+        }
+        return sub<8>(v, m8, lc, surv);
+    }
 };
 
-template <int LEV, int NLOG, int LMAX>
+template <int LEV, int NLOG, int LMAX, bool V2>
 __device__ __forceinline__ void scl_node(SclReg<NLOG, LMAX> &d, uint32_t maskv, const float *chan_lane, uint32_t idx, int plane,
-                                         const LaneConst &lc, uint32_t *surv)
+                                         const LaneConst &lc, uint32_t *surv PROF_ARGS)
 {
 #pragma nounroll
     for (uint32_t h = 0; h < 2; h++) {
         if (h == 0) d.template step_f<LEV>(chan_lane, lc);
         else d.template step_g<LEV>(chan_lane, lc);
+        PROF_ADD(LEV);  // categories 4 .. 10: the f / g steps of that level
         const uint32_t cidx = 2 * idx + h;
         if constexpr (LEV - 1 == 3) {
             const uint32_t mw = (uint32_t)__builtin_amdgcn_readlane((int)maskv, (int)(cidx >> 2));
             const uint32_t m8 = (mw >> (8 * (cidx & 3))) & 0xFFu;
-            const uint32_t x = d.template sub<8>(d.R[1], m8, lc, surv);
+            const uint32_t x = V2 ? d.node8(d.R[1], m8, lc, surv) : d.template sub<8>(d.R[1], m8, lc, surv);
+            PROF_ADD(12 + __builtin_popcount(m8));  // categories 12 .. 20: 8-leaf nodes by their number of information bits
             if (h) {
                 d.b0 = (d.b0 & ~(uint64_t)2) | ((uint64_t)x << 1);
             } else {
@@ -366,20 +539,25 @@ __device__ __forceinline__ void scl_node(SclReg<NLOG, LMAX> &d, uint32_t maskv, 
                 d.st.ownP = SclReg<NLOG, LMAX>::own_set(d.st.ownP, 3, (uint32_t)lc.p);
             }
         } else {
-            scl_node<LEV - 1, NLOG, LMAX>(d, maskv, chan_lane, cidx, (int)h, lc, surv);
+            scl_node<LEV - 1, NLOG, LMAX, V2>(d, maskv, chan_lane, cidx, (int)h, lc, surv PROF_PASS);
         }
     }
     d.template combine<LEV>(plane, lc);
+    PROF_ADD(11);  // combines
 }
 
-template <int NLOG, int LMAX>
-__global__ void __launch_bounds__(64, NLOG == 10 ? 3 : 2) scl_reg_kernel(const float *__restrict__ llr, const uint32_t *__restrict__ maskw,
+template <int NLOG, int LMAX, bool V2>
+__global__ void __launch_bounds__(64, NLOG == 10 ? 3 : 4) scl_reg_kernel(const float *__restrict__ llr, const uint32_t *__restrict__ maskw,
                                                         const uint16_t *__restrict__ Asl8, const uint32_t *__restrict__ crcS,
                                                         const uint32_t *__restrict__ truth, uint32_t *__restrict__ info_hat, int64_t B,
                                                         int K, int Kw, float *__restrict__ slab)
 {
-    __shared__ uint32_t surv[8];
-    __shared__ uint32_t stage[64 * 4];  // 8 paths x 8 lanes x 128-bit slice of u_hat
+    // exchange records of the pruning step (6 words per lane, word-major); its first words double as the survivor table of
+    // the general leaf, and the whole area as the staging buffer of the output stage (8 paths x 8 lanes x 128-bit slice of u_hat)
+    __shared__ uint32_t xchg[64 * 6];
+    uint32_t *const surv = xchg;
+    uint32_t *const stage = xchg;
+    uint32_t *const passw = xchg + 320;  // bitmap of the list entries that pass the CRC / equal the transmitted word
     constexpr int N = 1 << NLOG;
     __shared__ uint16_t asl_s[N];       // the gather table of the output stage (the CRC remainders stay in global memory)
     __shared__ float lvl_s[SclStore<NLOG>::LDS_VALUES];
@@ -395,6 +573,20 @@ __global__ void __launch_bounds__(64, NLOG == 10 ? 3 : 2) scl_reg_kernel(const f
         lc.up[i] = (lc.e & (4 >> i)) != 0;
         lc.lowmask[i] = lc.up[i] ? 0u : 1u;
     }
+    {
+        const int bme = lc.q >> 2, k = lc.q & 3, cpos = bme ? lc.p : 8 + lc.p;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int op = 2 * k + (i >> 1), ob = i & 1;
+            lc.rsrc[i] = (op * 8 + 4 * ob) << 2;
+            // candidates of empty positions (list sizes below 8) come after every real one
+            const int opos = (ob ? op : 8 + op) + ((LMAX == 8 || op < LMAX) ? 0 : 16);
+            lc.rsub[i] = opos < cpos + ((LMAX == 8 || lc.p < LMAX) ? 0 : 16) ? 1u : 0u;
+        }
+        lc.keepflip = bme ? 0u : 1u;
+        lc.ubit[0] = (uint32_t)bme << 31;
+        lc.ubit[1] = (uint32_t)(1 - bme) << 31;
+    }
     const uint32_t maskv = maskw[(lc.lane & 31) < (N / 32) ? (lc.lane & 31) : 0];
     SclReg<NLOG, LMAX> d;
     d.my_lane = lc.lane;
@@ -409,7 +601,8 @@ __global__ void __launch_bounds__(64, NLOG == 10 ? 3 : 2) scl_reg_kernel(const f
 #pragma unroll
         for (int i = 0; i < 3; i++) d.st.v[i] = 0.0f;
         d.Lcur = 1;
-        scl_node<NLOG, NLOG, LMAX>(d, maskv, chan_lane, 0u, 0, lc, surv);
+        PROF_DECL;
+        scl_node<NLOG, NLOG, LMAX, V2>(d, maskv, chan_lane, 0u, 0, lc, surv PROF_PASS);
 
         // final stable descending order: rank of every position; the best path is rank 0
         const bool act = lc.p < d.Lcur;
@@ -479,11 +672,11 @@ __global__ void __launch_bounds__(64, NLOG == 10 ? 3 : 2) scl_reg_kernel(const f
                     syn ^= partner8_u<4>(syn);
                     syn ^= partner8_u<8>(syn);
                 }
-                if (lc.lane == 0) surv[0] = 0u;
+                if (lc.lane == 0) passw[0] = 0u;
                 wave_sync();
-                if (lc.q == 0 && act && syn == 0u) atomicOr(&surv[0], 1u << rank);
+                if (lc.q == 0 && act && syn == 0u) atomicOr(&passw[0], 1u << rank);
                 wave_sync();
-                const uint32_t pass = surv[0];
+                const uint32_t pass = passw[0];
                 sel = pass ? __ffs(pass) - 1 : 0;
             }
             const bool best = act && rank == sel;
@@ -495,8 +688,25 @@ __global__ void __launch_bounds__(64, NLOG == 10 ? 3 : 2) scl_reg_kernel(const f
             if (K == 0 && lc.lane == 0) dst[0] = 0u;
         }
         wave_sync();
+#ifdef POLAR_SCL_PROFILE
+        PROF_ADD(21);  // output stage
+        if (lc.lane == 0)
+            for (int i = 0; i < 24; i++) atomicAdd(&g_scl_prof[i], prof_acc[i]);
+#endif
     }
 }
+
+#ifdef POLAR_SCL_PROFILE
+extern "C" __attribute__((visibility("default"))) int polar_debug_scl_profile(unsigned long long *out, int clear)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scl_prof), sizeof(unsigned long long) * 24) != hipSuccess) return -1;
+    if (clear) {
+        unsigned long long z[64] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_scl_prof), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 // ------------------------------------------------------------------------------------------ host side
 bool scl_reg_supported(const polar_code *c, int dtype, int L, const void *pm, const void *u_hat_all)
@@ -512,7 +722,10 @@ template <int NLOG, int LMAX>
 static int launch_scl_reg_t(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, bool crc, const uint32_t *truth)
 {
     polar_ctx *ctx = c->ctx;
-    auto kern = scl_reg_kernel<NLOG, LMAX>;
+    // POLAR_SCL_KERNEL=reg1: the form that interprets the rate profile leaf by leaf (kept for comparison)
+    const char *ke = getenv("POLAR_SCL_KERNEL");
+    const bool v1 = ke && strcmp(ke, "reg1") == 0;
+    auto kern = v1 ? scl_reg_kernel<NLOG, LMAX, false> : scl_reg_kernel<NLOG, LMAX, true>;
     // POLAR_SCL_LDSPAD (bytes of unused dynamic LDS per wavefront) lowers the occupancy for experiments
     const char *pe = getenv("POLAR_SCL_LDSPAD");
     const size_t pad = pe ? (size_t)atoi(pe) : 0;
@@ -530,7 +743,7 @@ static int launch_scl_reg_t(polar_code *c, const void *llr, uint32_t *info_hat, 
                        ctx->scl_slab.as<float>());
     HIP_TRY(hipGetLastError());
     float ms = tm.stop();
-    snprintf(c->last.kernel, sizeof(c->last.kernel), "scl_reg_kernel<%d>/L%d", NLOG, LMAX);
+    snprintf(c->last.kernel, sizeof(c->last.kernel), "scl_reg_kernel<%d>/L%d%s", NLOG, LMAX, v1 ? "/v1" : "");
     c->last.lanes_per_frame = 64;
     c->last.lds_bytes_per_block = 32 + 1024 + 2 * c->N + 4 * SclStore<NLOG>::LDS_VALUES;
     c->last.block_threads = 64;

@@ -2,6 +2,7 @@
 // The arithmetic lives in the kernels_*.hip files.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -281,43 +282,60 @@ extern "C" int polar_code_set_crc(polar_code *c, uint64_t crc_poly)
 {
     ARG_TRY(c != nullptr, "code is NULL");
     HIP_TRY(hipSetDevice(c->ctx->device));
-    HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+    // the new tables are validated, built and uploaded first; the code keeps its old CRC if anything fails
+    uint32_t *nE = nullptr, *nS = nullptr;
+    int w = 0;
+    if (crc_poly != 0) {
+        w = 63 - __builtin_clzll(crc_poly);
+        ARG_TRY(w >= 1 && w <= 32, "CRC width (degree of crc_poly) must be in [1, 32]");
+        ARG_TRY(w <= c->K, "CRC is wider than the code's information length");
+        const uint64_t keep = (1ull << w) - 1ull;
+        const uint64_t low = crc_poly & keep;
+        // R[p] = x^(p + w) mod g: what a one at distance p from the end of a word leaves in the remainder register
+        // of the MSB-first shift register after the word and w zeros went through (cn/functions.py:567-583)
+        std::vector<uint32_t> R(c->K);
+        uint64_t r = low;
+        for (int p = 0; p < c->K; p++) {
+            R[p] = (uint32_t)r;
+            const uint64_t top = (r >> (w - 1)) & 1ull;
+            r = ((r << 1) & keep) ^ (top ? low : 0ull);
+        }
+        const int Km = c->K - w;
+        std::vector<uint32_t> E(std::max(1, Km), 0), S(c->K);
+        for (int k = 0; k < Km; k++) {
+            uint32_t v = R[Km - 1 - k], t = 0;  // appended bit j is register bit w-1-j
+            for (int j = 0; j < w; j++) t |= ((v >> (w - 1 - j)) & 1u) << j;
+            E[k] = t;
+        }
+        for (int k = 0; k < c->K; k++) S[k] = R[c->K - 1 - k];
+        hipError_t e = hipMalloc((void **)&nE, E.size() * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&nS, S.size() * 4);
+        if (e == hipSuccess) e = hipMemcpy(nE, E.data(), E.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(nS, S.data(), S.size() * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            if (nE) (void)hipFree(nE);
+            if (nS) (void)hipFree(nS);
+            polar_set_error("uploading the CRC tables failed: %s", hipGetErrorString(e));
+            return POLAR_EHIP;
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(c->ctx->stream));  // launches that read the old tables have finished
     if (c->d_crcE) (void)hipFree(c->d_crcE);
     if (c->d_crcS) (void)hipFree(c->d_crcS);
-    c->d_crcE = c->d_crcS = nullptr;
-    c->crc_poly = 0;
-    c->crc_w = 0;
-    if (crc_poly == 0) return POLAR_OK;
-    int w = 63 - __builtin_clzll(crc_poly);
-    ARG_TRY(w >= 1 && w <= 32, "CRC width (degree of crc_poly) must be in [1, 32]");
-    ARG_TRY(w <= c->K, "CRC is wider than the code's information length");
-    const uint64_t keep = (w == 64) ? ~0ull : ((1ull << w) - 1ull);
-    const uint64_t low = crc_poly & keep;
-    // R[p] = x^(p + w) mod g: what a one at distance p from the end of a word leaves in the remainder register
-    // of the MSB-first shift register after the word and w zeros went through (cn/functions.py:567-583)
-    std::vector<uint32_t> R(c->K);
-    uint64_t r = low;
-    for (int p = 0; p < c->K; p++) {
-        R[p] = (uint32_t)r;
-        const uint64_t top = (r >> (w - 1)) & 1ull;
-        r = ((r << 1) & keep) ^ (top ? low : 0ull);
-    }
-    const int Km = c->K - w;
-    std::vector<uint32_t> E(std::max(1, Km), 0), S(c->K);
-    for (int k = 0; k < Km; k++) {
-        uint32_t v = R[Km - 1 - k], t = 0;  // appended bit j is register bit w-1-j
-        for (int j = 0; j < w; j++) t |= ((v >> (w - 1 - j)) & 1u) << j;
-        E[k] = t;
-    }
-    for (int k = 0; k < c->K; k++) S[k] = R[c->K - 1 - k];
-    HIP_TRY(hipMalloc((void **)&c->d_crcE, E.size() * 4));
-    HIP_TRY(hipMalloc((void **)&c->d_crcS, S.size() * 4));
-    HIP_TRY(hipMemcpy(c->d_crcE, E.data(), E.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->d_crcS, S.data(), S.size() * 4, hipMemcpyHostToDevice));
+    c->d_crcE = nE;
+    c->d_crcS = nS;
     c->crc_poly = crc_poly;
     c->crc_w = w;
     return POLAR_OK;
 }
+// the list and flip decoders keep a frame's whole tree in one wavefront's LDS and 12 pointer levels per path
+#define N_LIMIT_TRY(c, what)                                                                          \
+    do {                                                                                              \
+        if ((c)->n > 12) {                                                                            \
+            polar_set_error("%s: N=%d exceeds the supported maximum of 4096", what, (c)->N);         \
+            return POLAR_EUNSUPPORTED;                                                                \
+        }                                                                                             \
+    } while (0)
 #define CRC_TRY(c, flags) ARG_TRY(!((flags)&POLAR_CRC) || (c)->crc_w > 0, "POLAR_CRC needs polar_code_set_crc first")
 
 extern "C" int polar_last_launch(polar_code *c, polar_launch_info *out)
@@ -522,6 +540,7 @@ static int scl_common(polar_code *c, const void *llr, int dtype, int L, void *in
     ARG_TRY(llr != nullptr, "llr is NULL");
     ARG_TRY(dtype == POLAR_F32 || dtype == POLAR_F64, "dtype must be POLAR_F32 or POLAR_F64");
     ARG_TRY(L == 1 || L == 2 || L == 4 || L == 8 || L == 16 || L == 32, "L must be a power of two in [1, 32]");
+    N_LIMIT_TRY(c, "list decoder");
     polar_ctx *ctx = c->ctx;
     const size_t es = llr_size(dtype);
     if (space == POLAR_DEVICE && packed)
@@ -732,6 +751,7 @@ static int pbf_common(polar_code *c, const void *llr, int dtype, int max_level, 
     ARG_TRY(max_level >= 0 && max_level <= 3, "max_level must be in [0, 3]");
     ARG_TRY(c->crc_w > 0, "bit flipping needs polar_code_set_crc first");
     ARG_TRY(max_level == 0 || c->have_mu, "bit flipping needs polar_code_set_reliability first");
+    N_LIMIT_TRY(c, "flip decoder");
     polar_ctx *ctx = c->ctx;
     const size_t es = llr_size(dtype);
     int rc;
@@ -849,6 +869,7 @@ extern "C" int polar_sc_decode_flip(polar_code *c, const void *llr, int dtype, c
     CHECK_COMMON(c, B, space);
     ARG_TRY(llr && flips, "NULL buffer");
     ARG_TRY(dtype == POLAR_F32 || dtype == POLAR_F64, "dtype must be POLAR_F32 or POLAR_F64");
+    N_LIMIT_TRY(c, "flip decoder");
     polar_ctx *ctx = c->ctx;
     const size_t es = llr_size(dtype);
     int rc;
@@ -941,6 +962,17 @@ extern "C" int polar_sc_decode_count(polar_code *c, const void *llr, int dtype, 
     return sc_decode_count(c, llr, dtype, info, info_hat, B, flags, counters, (flags & POLAR_CRC) ? c->K - c->crc_w : c->K);
 }
 
+// Frames per chunk of the Monte-Carlo loop: `deflt`, or POLAR_MC_CHUNK when set (tests use it to reach the
+// double-buffered pipeline with small runs)
+static int64_t mc_chunk_limit(int64_t deflt)
+{
+    if (const char *e = getenv("POLAR_MC_CHUNK")) {
+        const long long v = atoll(e);
+        if (v > 0) return std::min<int64_t>(deflt, (int64_t)v);
+    }
+    return deflt;
+}
+
 extern "C" int polar_mc_run(polar_code *c, int decoder, int L, int dtype, int flags, double N0, uint64_t seed,
                             uint64_t frame0, int64_t nframes, uint64_t counters[3])
 {
@@ -961,6 +993,7 @@ extern "C" int polar_mc_run(polar_code *c, int decoder, int L, int dtype, int fl
     }
     ARG_TRY(!((flags & POLAR_GENIE) && decoder != POLAR_DEC_SCL), "POLAR_GENIE goes with the list decoder");
     ARG_TRY(!((flags & POLAR_GENIE) && (flags & POLAR_CRC)), "POLAR_GENIE and POLAR_CRC exclude each other");
+    if (decoder != POLAR_DEC_SC) N_LIMIT_TRY(c, decoder == POLAR_DEC_PBF ? "flip decoder" : "list decoder");
     const bool crc = (flags & POLAR_CRC) != 0;
     polar_ctx *ctx = c->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -975,7 +1008,11 @@ extern "C" int polar_mc_run(polar_code *c, int decoder, int L, int dtype, int fl
             if ((rc = ctx->counters.reserve(3 * sizeof(uint64_t)))) return rc;
             uint64_t *dcnt = ctx->counters.as<uint64_t>();
             HIP_TRY(hipMemsetAsync(dcnt, 0, 3 * sizeof(uint64_t), ctx->stream));
-            if ((rc = launch_sc_static_mc(c, nframes, N0, seed, frame0, dcnt))) return rc;
+            // the kernel keeps its error sums in 32-bit lane registers until it ends: at most 2^30 frames (or the
+            // POLAR_MC_CHUNK of the tests) per launch, so that no run length can wrap them
+            const int64_t per = mc_chunk_limit((int64_t)1 << 30);
+            for (int64_t f0 = 0; f0 < nframes; f0 += per)
+                if ((rc = launch_sc_static_mc(c, std::min(per, nframes - f0), N0, seed, frame0 + f0, dcnt))) return rc;
             uint64_t h[3];
             HIP_TRY(hipMemcpyAsync(h, dcnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -985,7 +1022,7 @@ extern "C" int polar_mc_run(polar_code *c, int decoder, int L, int dtype, int fl
     }
     // chunks of about 4 GiB of LLRs (10^6 frames at N = 1024: long enough that the kernels' tails do not count), two buffers: chunk i+1 is generated on its own stream while chunk i is
     // decoded and counted (the decoders leave registers and issue slots free that the generator can use)
-    int64_t chunk = std::max<int64_t>(1024, ((int64_t)1 << 32) / ((int64_t)c->N * (int64_t)es));
+    int64_t chunk = mc_chunk_limit(std::max<int64_t>(1024, ((int64_t)1 << 32) / ((int64_t)c->N * (int64_t)es)));
     chunk = std::min(chunk, nframes);
     const bool two = nframes > chunk;
     int rc;

@@ -358,3 +358,32 @@ def test_sc_decode_count_fused_equals_two_kernels(N, K, dtype):
             assert got.cpu().tolist() == ref.cpu().tolist(), (spec, store)
             if store:
                 assert torch.equal(hat2, hat)
+
+
+@pytest.mark.parametrize("decoder", ["sc", "sc_staged", "scl", "pbf"])
+def test_mc_run_chunked_pipeline_counts_like_one_chunk(monkeypatch, decoder):
+    """polar_mc_run in several chunks (POLAR_MC_CHUNK caps the chunk: generator and decoder then overlap on two streams and
+    two buffers, ordered by events) counts exactly what one chunk counts."""
+    N, K = 256, 128
+    if decoder == "pbf":
+        K += 8
+    code = _native.Code(_native.default_ctx(), pcf.degaBuild(N, K, 2.0))
+    n0 = 1.0 / ((128 / N) * 10 ** (1.5 / 10))
+    dec, L, kw = _native.DEC_SC, 1, {}
+    if decoder == "scl":
+        dec, L = _native.DEC_SCL, 4
+    elif decoder == "pbf":
+        code.set_crc(0x107)
+        code.set_reliability(pcf.GA(N, K, 2.0))
+        dec, L, kw = _native.DEC_PBF, 1, {"crc": True}
+    elif decoder == "sc":
+        code.specialize()
+    else:
+        monkeypatch.setenv("POLAR_MC_KERNEL", "staged")
+    nfr = 5 * 4096 + 777
+    monkeypatch.delenv("POLAR_MC_CHUNK", raising=False)
+    one = code.mc_run(dec, L, np.float32, n0, 99, 12345, nfr, **kw)
+    monkeypatch.setenv("POLAR_MC_CHUNK", "4096")
+    many = code.mc_run(dec, L, np.float32, n0, 99, 12345, nfr, **kw)
+    assert int(one[0]) == nfr and one[1] > 0
+    assert one.tolist() == many.tolist()

@@ -307,10 +307,15 @@ def gen_curves(functions, polarCode, channel):
         ("scl4_128_64", 128, 64, "dega", 2.0, "scl", 4, [1.0, 2.0, 3.0], 6000),
     ]
     out = {}
+    dest = os.environ.get("GOLDEN_CURVES_OUT", os.path.join(OUT, "curves.npz"))
+    if os.environ.get("GOLDEN_CURVES_RESUME") and os.path.exists(dest):  # keep the points an interrupted run finished
+        out = dict(np.load(dest, allow_pickle=False))
     with mp.Pool(nproc) as pool:
         for (tag, N, K, cons, ds, dec, L, snrs, nfr) in plan:
-            rows = []
+            rows = [tuple(r) for r in out.get(tag, [])]
             for snr in snrs:
+                if any(r[0] == snr for r in rows):
+                    continue
                 t0 = time.time()
                 per = nfr // nproc
                 jobs = [(N, K, cons, ds, dec, L, snr, 100000 * (1 + j) + int(snr * 1000), per) for j in range(nproc)]
@@ -321,8 +326,8 @@ def gen_curves(functions, polarCode, channel):
                 be2 = sum(r[3] for r in res)
                 rows.append((snr, fr, fe, be, be2))  # be2 = sum of squared per-frame bit errors
                 print(f"curve {tag} {snr} dB: frames {fr} fe {fe} be {be} ({time.time()-t0:.0f}s)", flush=True)
-            out[tag] = np.array(rows, dtype=np.float64)
-            np.savez_compressed(os.environ.get("GOLDEN_CURVES_OUT", os.path.join(OUT, "curves.npz")), **out)
+                out[tag] = np.array(rows, dtype=np.float64)
+                np.savez_compressed(dest, **out)
 
 
 # --------------------------------------------------------------------------- main.py flow (bit-reversed variant)
