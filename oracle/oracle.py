@@ -133,6 +133,14 @@ def scl_decode(llr, mask, L):
     return uh[:n], pm[:n], cnt
 
 
+def scl_last_min_gap():
+    """Smallest relative gap between neighbouring candidate metrics in the prunes and the final sort of the last
+    scl_decode call of this thread (inf if there was none): how small a metric error could have changed a choice."""
+    fn = lib().orc_scl_last_min_gap
+    fn.restype = C.c_double
+    return float(fn())
+
+
 def extract(uhat, mask):
     return np.asarray(uhat)[..., np.asarray(mask) != 0]
 

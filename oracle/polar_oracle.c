@@ -205,6 +205,23 @@ static double branch_metric_f32(float llr, int u)
 
 typedef struct { double pm; int pos; } cand_key;
 
+/* Sensitivity of the last orc_scl_decode_* call of this thread to small errors of the metrics: the smallest gap
+ * between metrics that are neighbours in a sorted candidate list (every prune, and the final sort), relative to
+ * max(|metric|, 1); pairs of -inf are ordered by position alone and do not count.  A decoder whose metrics differ
+ * from the oracle's by less than half of this makes the same choices. */
+static __thread double orc_last_gap = 0.0;
+ORC_API double orc_scl_last_min_gap(void) { return orc_last_gap; }
+static void note_gaps(const double *sorted_desc, int n)
+{
+    for (int c = 0; c + 1 < n; c++) {
+        double a = sorted_desc[c], b = sorted_desc[c + 1];
+        if (isinf(a) || isinf(b)) continue;
+        double sc = fabs(a) > 1.0 ? fabs(a) : 1.0, sb = fabs(b) > 1.0 ? fabs(b) : 1.0;
+        double g = (a - b) / (sc > sb ? sc : sb);
+        if (g < orc_last_gap) orc_last_gap = g;
+    }
+}
+
 /* cn/polarCode.py:2032-2102 (sclDecoder) with :969-1005 (polarSCLFork).
  * List order is kept exactly: below saturation list = originals ++ copies; at saturation the
  * candidates are copies(u=1) ++ originals(u=0), stable-sorted by metric descending, first L kept in
@@ -220,6 +237,7 @@ typedef struct { double pm; int pos; } cand_key;
         for (int j = 0; j < 2 * L; j++) path_alloc_##SUF(&list[j], N);                                \
         int cur = 1;                                                                                  \
         int64_t anv = 0, sortnum = 0, unit = 0;                                                       \
+        orc_last_gap = INFINITY;                                                                      \
         memcpy(list[0].llr + (N - 1), llr, (size_t)N * sizeof(REAL));                                 \
         for (int i = 0; i < N; i++) {                                                                 \
             for (int j = 0; j < cur; j++) { unit += update_llrs_##SUF(&list[j], i, n); anv++; }       \
@@ -248,6 +266,7 @@ typedef struct { double pm; int pos; } cand_key;
                     sortnum++;                                                                        \
                     for (int c = 0; c < nc; c++) tmp[c] = list[order[c]];                             \
                     for (int c = 0; c < nc; c++) list[c] = tmp[c];                                    \
+                    { double sp[128]; for (int c = 0; c < nc; c++) sp[c] = list[c].pm; note_gaps(sp, nc); } \
                     cur = L;                                                                          \
                 }                                                                                     \
             } else {                                                                                  \
@@ -272,6 +291,7 @@ typedef struct { double pm; int pos; } cand_key;
                 memcpy(uhat_all + (size_t)c * N, list[order[c]].uhat, N);                             \
                 pm_all[c] = list[order[c]].pm;                                                        \
             }                                                                                         \
+            note_gaps(pm_all, cur);                                                                                         \
         }                                                                                             \
         if (counts) { counts[0] = anv; counts[1] = sortnum; counts[2] = unit; }                       \
         for (int j = 0; j < 2 * L; j++) path_free_##SUF(&list[j]);                                    \

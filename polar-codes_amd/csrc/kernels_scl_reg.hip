@@ -517,7 +517,7 @@ template <int NLOG, int LMAX = 8> struct SclReg {
     }
 };
 
-template <int LEV, int NLOG, int LMAX, bool V2>
+template <int LEV, int NLOG, int LMAX>
 __device__ __forceinline__ void scl_node(SclReg<NLOG, LMAX> &d, uint32_t maskv, const float *chan_lane, uint32_t idx, int plane,
                                          const LaneConst &lc, uint32_t *surv PROF_ARGS)
 {
@@ -530,7 +530,7 @@ __device__ __forceinline__ void scl_node(SclReg<NLOG, LMAX> &d, uint32_t maskv, 
         if constexpr (LEV - 1 == 3) {
             const uint32_t mw = (uint32_t)__builtin_amdgcn_readlane((int)maskv, (int)(cidx >> 2));
             const uint32_t m8 = (mw >> (8 * (cidx & 3))) & 0xFFu;
-            const uint32_t x = V2 ? d.node8(d.R[1], m8, lc, surv) : d.template sub<8>(d.R[1], m8, lc, surv);
+            const uint32_t x = d.node8(d.R[1], m8, lc, surv);
             PROF_ADD(12 + __builtin_popcount(m8));  // categories 12 .. 20: 8-leaf nodes by their number of information bits
             if (h) {
                 d.b0 = (d.b0 & ~(uint64_t)2) | ((uint64_t)x << 1);
@@ -539,14 +539,14 @@ __device__ __forceinline__ void scl_node(SclReg<NLOG, LMAX> &d, uint32_t maskv, 
                 d.st.ownP = SclReg<NLOG, LMAX>::own_set(d.st.ownP, 3, (uint32_t)lc.p);
             }
         } else {
-            scl_node<LEV - 1, NLOG, LMAX, V2>(d, maskv, chan_lane, cidx, (int)h, lc, surv PROF_PASS);
+            scl_node<LEV - 1, NLOG, LMAX>(d, maskv, chan_lane, cidx, (int)h, lc, surv PROF_PASS);
         }
     }
     d.template combine<LEV>(plane, lc);
     PROF_ADD(11);  // combines
 }
 
-template <int NLOG, int LMAX, bool V2>
+template <int NLOG, int LMAX>
 __global__ void __launch_bounds__(64, NLOG == 10 ? 3 : 4) scl_reg_kernel(const float *__restrict__ llr, const uint32_t *__restrict__ maskw,
                                                         const uint16_t *__restrict__ Asl8, const uint32_t *__restrict__ crcS,
                                                         const uint32_t *__restrict__ truth, uint32_t *__restrict__ info_hat, int64_t B,
@@ -602,7 +602,7 @@ __global__ void __launch_bounds__(64, NLOG == 10 ? 3 : 4) scl_reg_kernel(const f
         for (int i = 0; i < 3; i++) d.st.v[i] = 0.0f;
         d.Lcur = 1;
         PROF_DECL;
-        scl_node<NLOG, NLOG, LMAX, V2>(d, maskv, chan_lane, 0u, 0, lc, surv PROF_PASS);
+        scl_node<NLOG, NLOG, LMAX>(d, maskv, chan_lane, 0u, 0, lc, surv PROF_PASS);
 
         // final stable descending order: rank of every position; the best path is rank 0
         const bool act = lc.p < d.Lcur;
@@ -722,10 +722,7 @@ template <int NLOG, int LMAX>
 static int launch_scl_reg_t(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, bool crc, const uint32_t *truth)
 {
     polar_ctx *ctx = c->ctx;
-    // POLAR_SCL_KERNEL=reg1: the form that interprets the rate profile leaf by leaf (kept for comparison)
-    const char *ke = getenv("POLAR_SCL_KERNEL");
-    const bool v1 = ke && strcmp(ke, "reg1") == 0;
-    auto kern = v1 ? scl_reg_kernel<NLOG, LMAX, false> : scl_reg_kernel<NLOG, LMAX, true>;
+    auto kern = scl_reg_kernel<NLOG, LMAX>;
     // POLAR_SCL_LDSPAD (bytes of unused dynamic LDS per wavefront) lowers the occupancy for experiments
     const char *pe = getenv("POLAR_SCL_LDSPAD");
     const size_t pad = pe ? (size_t)atoi(pe) : 0;
@@ -743,7 +740,7 @@ static int launch_scl_reg_t(polar_code *c, const void *llr, uint32_t *info_hat, 
                        ctx->scl_slab.as<float>());
     HIP_TRY(hipGetLastError());
     float ms = tm.stop();
-    snprintf(c->last.kernel, sizeof(c->last.kernel), "scl_reg_kernel<%d>/L%d%s", NLOG, LMAX, v1 ? "/v1" : "");
+    snprintf(c->last.kernel, sizeof(c->last.kernel), "scl_reg_kernel<%d>/L%d", NLOG, LMAX);
     c->last.lanes_per_frame = 64;
     c->last.lds_bytes_per_block = 32 + 1024 + 2 * c->N + 4 * SclStore<NLOG>::LDS_VALUES;
     c->last.block_threads = 64;
