@@ -149,22 +149,12 @@ struct ChannelGen {
     float sigma, gain;
     int sub;
 };
-// WIDE (N >= 512, channel read from memory): the channel does not come in as 4-byte loads of the lane's own elements
-// (a frame's 16 lanes then fetch 64 contiguous bytes per instruction) but as 16-byte loads of whole kilobytes, one
-// frame and one contiguous quarter-kilo-element range per instruction, staged through LDS: a chunk is the 16 pairs
-// per lane that two such ranges (elements 256 ch .. 256 ch + 255 and their partners N/2 further) hold for the four
-// frames of the wavefront, 8 KB.  Chunks go through the same buffer one after the other; all but the last end in the
-// registers CA / CB, the last one stays in the buffer for the top-level g (so KEEP = pairs - 16).
-constexpr int WIDE_FS = 528;  // floats per frame in the staging buffer: 2 x 256 and 16 of padding, which turns the banks by 16 per frame
-template <int NLOG_, int KEEP = 0, int KL = 0, bool GEN = false, bool WIDE = false> struct StaticDec {
+template <int NLOG_, int KEEP = 0, int KL = 0, bool GEN = false> struct StaticDec {
     static constexpr int NLOG = NLOG_;
     static constexpr int S = 1 << (NLOG - 4);
     float R[S];
     float CA[KEEP > 0 ? KEEP : 1], CB[KEEP > 0 ? KEEP : 1];
     float *kept;
-    const float *wsrc[4];  // WIDE: channel LLRs of the wavefront's four frames (wave-uniform pointers)
-    float *wbuf;           // WIDE: the wavefront's staging buffer (4 x WIDE_FS floats)
-    int wlane;             // WIDE: lane number
     uint32_t X[NLOG - 4][2];
     ps_t root;  // element j at bit j, as the output stage takes it
     ChannelGen cg;
@@ -236,45 +226,6 @@ template <int NLOG_, int KEEP = 0, int KL = 0, bool GEN = false, bool WIDE = fal
         static_for<0, c / 4>(group);
     }
 
-    // top-level f of the WIDE form: every load of the four frames is issued first, then chunk after chunk goes through
-    // the buffer
-    __device__ __forceinline__ void top_f_wide()
-    {
-        constexpr int c = 1 << (NLOG - 5);
-        constexpr int NCH = c / 16;
-        constexpr int HALF = 1 << (NLOG - 1);
-        static_assert(!WIDE || (NCH >= 1 && KEEP >= c - 16 && !GEN), "wide channel loads: all chunks but the last end in registers");
-        auto load = [&](int ch, float4 *st) {
-#pragma unroll
-            for (int g = 0; g < 4; g++)
-#pragma unroll
-                for (int h = 0; h < 2; h++)
-                    st[2 * g + h] = *reinterpret_cast<const float4 *>(wsrc[g] + h * HALF + ch * 256 + 4 * wlane);
-        };
-        const float *rd = wbuf + (wlane >> 4) * WIDE_FS + (wlane & 15);
-#pragma unroll
-        for (int ch = 0; ch < NCH; ch++) {
-            float4 cur[8];
-            load(ch, cur);
-            wave_sync();  // the buffer's previous contents have been read
-#pragma unroll
-            for (int g = 0; g < 4; g++)
-#pragma unroll
-                for (int h = 0; h < 2; h++) *reinterpret_cast<float4 *>(wbuf + g * WIDE_FS + h * 256 + 4 * wlane) = cur[2 * g + h];
-            wave_sync();
-#pragma unroll
-            for (int jj = 0; jj < 16; jj++) {
-                const int j = 16 * ch + jj;
-                const float a = rd[16 * jj], b = rd[256 + 16 * jj];
-                if (j < KEEP) {
-                    CA[j] = a;
-                    CB[j] = b;
-                }
-                R[c + j] = f_fast(a, b);
-            }
-        }
-    }
-
     template <int LEV, bool IS_G> __device__ __forceinline__ void step(const float *chan_lane)
     {
         constexpr int c = 1 << (LEV - 5);
@@ -282,11 +233,7 @@ template <int NLOG_, int KEEP = 0, int KL = 0, bool GEN = false, bool WIDE = fal
             top_f_generate();
             return;
         }
-        if constexpr (WIDE && LEV == NLOG && !IS_G) {
-            top_f_wide();
-            return;
-        }
-        if constexpr (LEV == NLOG && IS_G && !GEN && !WIDE) {
+        if constexpr (LEV == NLOG && IS_G && !GEN) {
             // the second read of the channel goes through an offset the compiler cannot see is zero: reusing
             // the values of the first read would keep the whole slice in registers, KEEP decides how much of it is
             uint32_t zero = 0;
@@ -298,10 +245,6 @@ template <int NLOG_, int KEEP = 0, int KL = 0, bool GEN = false, bool WIDE = fal
                 if (IS_G && j < KEEP) {
                     a = CA[j];
                     b = CB[j];
-                } else if (WIDE) {  // top-level g: the last chunk is still in the staging buffer
-                    const float *rd = wbuf + (wlane >> 4) * WIDE_FS + (wlane & 15);
-                    a = rd[16 * (j - (c - 16))];
-                    b = rd[256 + 16 * (j - (c - 16))];
                 } else if (IS_G && j < KEEP + KL) {
                     a = kept[(2 * (j - KEEP)) * 64];
                     b = kept[(2 * (j - KEEP) + 1) * 64];
@@ -565,17 +508,12 @@ struct PolarStaticProfile {
 #ifndef POLAR_STATIC_WAVES
 #define POLAR_STATIC_WAVES 4
 #endif
-#ifndef POLAR_STATIC_WIDE
-#define POLAR_STATIC_WIDE 1
-#endif
 struct PolarStaticShape {
     static constexpr int NLOG = POLAR_STATIC_NLOG;
     static constexpr int PAIRS = 1 << (NLOG - 5);
     static constexpr int KEEP = POLAR_STATIC_KEEP < PAIRS ? POLAR_STATIC_KEEP : PAIRS;
     static constexpr int KL = (PAIRS - KEEP) < POLAR_STATIC_KEEP_LDS ? (PAIRS - KEEP) : POLAR_STATIC_KEEP_LDS;
-    // 16-byte channel loads staged through LDS: from N = 512 on, when all pairs but the last 16 stay in registers
-    static constexpr bool WIDE = POLAR_STATIC_WIDE != 0 && NLOG >= 9 && KEEP == PAIRS - 16 + (PAIRS == 16 ? 16 : 0);
-    static constexpr int KEPT_WORDS = WIDE ? 4 * WIDE_FS : 2 * KL * 64;  // per wavefront
+    static constexpr int KEPT_WORDS = 2 * KL * 64;  // per wavefront
 };
 // Workgroups of SC_STATIC_WAVES wavefronts share the gather table; everything else is per wavefront (the wavefronts
 // of a workgroup never wait for each other after the table is loaded).
@@ -588,10 +526,10 @@ extern "C" __global__ void __launch_bounds__(64 * SC_STATIC_WAVES, POLAR_STATIC_
     constexpr int KEPT = PolarStaticShape::KEPT_WORDS;
     __shared__ __attribute__((aligned(32))) uint32_t stage_s[SC_STATIC_WAVES * SC_STAGE_WORDS];
     __shared__ uint16_t asl_s[GatherShape<NLOG>::WORDS];
-    __shared__ __attribute__((aligned(16))) float kept_s[SC_STATIC_WAVES * (KEPT > 0 ? KEPT : 1)];
+    __shared__ float kept_s[SC_STATIC_WAVES * (KEPT > 0 ? KEPT : 1)];
     for (int k = threadIdx.x; k < GatherShape<NLOG>::WORDS; k += 64 * SC_STATIC_WAVES) asl_s[k] = Asl[k];
     __syncthreads();
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: frame offsets stay in scalar registers
     const int lane = threadIdx.x & 63;
     const int grp = lane >> 4;
     const int sub = lane & 15;
@@ -604,20 +542,13 @@ extern "C" __global__ void __launch_bounds__(64 * SC_STATIC_WAVES, POLAR_STATIC_
         rc.lowmask[i] = rc.up[i] ? 0u : 0xFFFFFFFFu;
         rc.low31[i] = rc.up[i] ? 0u : 0x80000000u;
     }
-    constexpr bool WIDE = PolarStaticShape::WIDE;
-    StaticDec<NLOG, PolarStaticShape::KEEP, WIDE ? 0 : PolarStaticShape::KL, false, WIDE> d;
+    StaticDec<NLOG, PolarStaticShape::KEEP, PolarStaticShape::KL> d;
     d.kept = kept_s + wave * KEPT + lane;
-    d.wbuf = kept_s + wave * KEPT;
-    d.wlane = lane;
     const long long stride = (long long)gridDim.x * (4 * SC_STATIC_WAVES);
     for (long long f0 = ((long long)blockIdx.x * SC_STATIC_WAVES + wave) * 4; f0 < B; f0 += stride) {
         const long long f = f0 + grp;
         const bool active = f < B;
         const long long fc = active ? f : B - 1;
-        if constexpr (WIDE) {
-#pragma unroll
-            for (int g = 0; g < 4; g++) d.wsrc[g] = llr + (f0 + g < B ? f0 + g : B - 1) * N;  // rows past the end decode the last frame again
-        }
         decode_static<PolarStaticProfile, NLOG, 0, 0>(d, llr + fc * N + sub, rc);
         sc_reg_epilogue<NLOG>(d.root, stage, asl_s, info_hat, fc, active, lane, K, Kw, truth, nbits, &acc);
     }

@@ -20,7 +20,6 @@ static int compile_static(const uint8_t *mask, int N, const char *arch, std::vec
     // experiment knobs: channel pairs kept in registers / in LDS per lane, and the occupancy the compiler aims for
     if (const char *e = getenv("POLAR_STATIC_KEEP")) src += "#define POLAR_STATIC_KEEP " + std::to_string(atoi(e)) + "\n";
     if (const char *e = getenv("POLAR_STATIC_KEEP_LDS")) src += "#define POLAR_STATIC_KEEP_LDS " + std::to_string(atoi(e)) + "\n";
-    if (const char *e = getenv("POLAR_STATIC_WIDE")) src += "#define POLAR_STATIC_WIDE " + std::to_string(atoi(e)) + "\n";
     if (const char *e = getenv("POLAR_STATIC_WAVES")) src += "#define POLAR_STATIC_WAVES " + std::to_string(atoi(e)) + "\n";
     src += "#define POLAR_STATIC_NLOG " + std::to_string(n) + "\n#define POLAR_STATIC_WORDS ";
     for (int w = 0; w < (N + 31) / 32; w++) {
