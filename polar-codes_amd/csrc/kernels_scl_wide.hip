@@ -1,0 +1,532 @@
+// Register-resident list decoder for long lists: up to L = 32 paths (L = 16 leaves half of the positions empty),
+// N = 64 .. 512, fp32, information bits of the best path: one wavefront per frame, two lanes per path.
+//
+// Lane 2p + h belongs to list position p.  Element k of every tree level of a path lives in the lane with h = k & 1,
+// at index k >> 1, so the partners (k, k + half) of every f and g down to level 2 sit in one lane and are plain
+// register arithmetic; only the 2-leaf nodes exchange values between the two lanes of a path (one DPP swap).
+// Levels 1 .. 6 (63 values per lane) stay in registers, wider levels live lane-major in a slab of global memory
+// per wavefront (N = 512: levels 7 and 8, 48 KB, touched by twelve steps per frame); the channel LLRs, which every
+// path reads, are staged once per frame in LDS, split by parity.  Partial sums are bit slices in registers.
+//
+// Forking never copies a slice: as in the 8-lanes-per-path kernel (kernels_scl_reg.hip) every path keeps rows of
+// 5-bit "owner" positions per level for its LLRs and its left-child partial sums, all paths rewrite a level in
+// lockstep into their own registers, and g / combine fetch from the owner's lanes (ds_bpermute, or the owner's slots
+// of the slab).
+//
+// At an information bit lane 2p + h IS candidate (p, u = h): with 32 paths the 64 candidates fill the wavefront.
+// Every lane publishes an integer key with the order of its metric in LDS at its place in the candidate order
+// copies(u=1) ++ originals(u=0) and counts the keys larger than its own (16 broadcast reads of four keys).  Exactly
+// equal metrics are rare; they show as a missing or doubly claimed rank and send the wavefront through a second
+// count that adds the equal keys standing earlier in the candidate order -- the stable descending sort of the
+// reference's polarSCLFork (cn/polarCode.py:969-1005).  Rank r < L becomes list position r.
+// Metric, arithmetic and order of operations are those of scl_decode_kernel<float, L>: the two give the same bits.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "polar_internal.h"
+#include "reg_common.h"
+
+namespace {
+
+__device__ __forceinline__ float wb_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(lane << 2, __float_as_int(v))); }
+__device__ __forceinline__ uint32_t wb_u(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute(lane << 2, (int)v); }
+__device__ __forceinline__ uint64_t wb_u64(uint64_t v, int lane)
+{
+    return ((uint64_t)wb_u((uint32_t)(v >> 32), lane) << 32) | wb_u((uint32_t)v, lane);
+}
+__device__ __forceinline__ float swap2(float v) { return dpp_mov<0xB1>(v); }  // quad_perm:[1,0,3,2]: the other lane of my path
+
+// fp32 branch metric of deciding u at decision LLR v, as in the other list kernels (overflow-free; -inf only where the
+// reference overflows)
+__device__ __forceinline__ float wide_metric(float v, uint32_t u)
+{
+    const float Li = v * 1.44269504088896340736f;
+    const float e = u ? Li : -Li;
+    const float m = fmaxf(e, 0.0f);
+    const float r = 1.0f - (m + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(e))));
+    return e >= 1024.0f ? -INFINITY : r;
+}
+// integer with the order of the float (no NaN and no -0 occur among metrics)
+__device__ __forceinline__ uint32_t order_key(float v)
+{
+    const uint32_t x = __float_as_uint(v);
+    return x ^ ((uint32_t)((int32_t)x >> 31) | 0x80000000u);
+}
+
+template <int NLOG> struct WideStore {
+    static constexpr int TOP = NLOG - 1;                         // widest stored level
+    static constexpr int LDS_LEVEL = NLOG >= 8 ? 6 : 99;         // from N = 256 on level 6 (32 values per lane) lives in LDS, lane-major
+    static constexpr int LDS_VALUES = NLOG >= 8 ? 32 * 64 : 1;   // floats per wavefront
+    static constexpr int REG_TOP = NLOG >= 8 ? 5 : (TOP < 6 ? TOP : 6);  // levels 1 .. REG_TOP in registers
+    static constexpr int REG_VALUES = 1 << REG_TOP;              // level l: 2^(l-1) values at offset 2^(l-1)
+    static constexpr int mem_off(int l)                          // first slab row of level l (rows of 64 lanes)
+    {
+        int o = 0;
+        for (int i = 7; i < l; i++) o += 1 << (i - 1);
+        return o;
+    }
+    static constexpr int MEM_ROWS = TOP >= 7 ? mem_off(TOP + 1) : 0;
+};
+
+template <int NLOG, int LMAX> struct WideDec {
+    using St = WideStore<NLOG>;
+    static constexpr int N = 1 << NLOG;
+    float R[St::REG_VALUES];
+    float *memu;           // the wavefront's slab (wave-uniform)
+    float *lds6u;          // the wavefront's LDS level (wave-uniform)
+    const float *chs;      // the frame's channel LLRs in LDS, [parity][N/2], + my parity's half
+    int lane, p, h;
+    // partial sums per plane: a level whose nodes have C bits per lane sits in W[0] at bit offset C for C <= 32, in W[1]
+    // for C = 64, in W[2..3] for C = 128
+    uint64_t A[4], Bp[4], Rt[4];
+    float pm;
+    uint32_t oL[2], oP[2];  // owner rows, 5 bits per level: levels 1 .. 6 in word 0, from 7 on in word 1; oL[1] bit 31: see node2
+    float x;                // my element of the enclosing 2-leaf node's LLRs while its first leaf is decided
+    int Lcur;
+
+    template <int LEV> static __device__ __forceinline__ uint32_t own_get(const uint32_t *row)
+    {
+        return (LEV <= 6 ? row[0] >> (5 * (LEV - 1)) : row[1] >> (5 * (LEV - 7))) & 31u;
+    }
+    template <int LEV> static __device__ __forceinline__ void own_set(uint32_t *row, uint32_t pos)
+    {
+        if constexpr (LEV <= 6) row[0] = (row[0] & ~(31u << (5 * (LEV - 1)))) | (pos << (5 * (LEV - 1)));
+        else row[1] = (row[1] & ~(31u << (5 * (LEV - 7)))) | (pos << (5 * (LEV - 7)));
+    }
+
+    // Accesses to the levels in memory take the lane number through an opaque copy made inside the step (`lq`): their
+    // addresses are then formed there, base plus instruction offset, instead of being hoisted out of the frame loop
+    // as one 64-bit register pair per slab row.
+    static __device__ __forceinline__ int opaque(int v)
+    {
+        asm volatile("" : "+v"(v));
+        return v;
+    }
+    template <int L> __device__ __forceinline__ float ld_own(int j, int lq) const
+    {
+        if constexpr (L >= 7) return memu[(St::mem_off(L) + j) * 64 + lq];
+        else if constexpr (L == St::LDS_LEVEL) return lds6u[j * 64 + lq];
+        else return R[(1 << (L - 1)) + j];
+    }
+    template <int L> __device__ __forceinline__ float ld_from(int j, int src) const
+    {
+        if constexpr (L >= 7) return memu[(St::mem_off(L) + j) * 64 + src];
+        else if constexpr (L == St::LDS_LEVEL) return lds6u[j * 64 + src];
+        else return wb_f(R[(1 << (L - 1)) + j], src);
+    }
+    template <int L> __device__ __forceinline__ void st_own(int j, float v, int lq)
+    {
+        if constexpr (L >= 7) memu[(St::mem_off(L) + j) * 64 + lq] = v;
+        else if constexpr (L == St::LDS_LEVEL) lds6u[j * 64 + lq] = v;
+        else R[(1 << (L - 1)) + j] = v;
+    }
+    template <int L> static __device__ __forceinline__ void level_written()
+    {
+        if constexpr (L >= 7) {  // other lanes of the wavefront read the slab rows next
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        } else if constexpr (L == St::LDS_LEVEL) {
+            wave_sync();
+        }
+    }
+
+    // ---- bit slices -----------------------------------------------------------------------------------------
+    struct Bits {
+        uint64_t w[2];
+    };
+    template <int C> static __device__ __forceinline__ Bits get_bits(const uint64_t *W)
+    {
+        Bits b{{0, 0}};
+        if constexpr (C <= 32) b.w[0] = (W[0] >> C) & ((((uint64_t)1) << C) - 1);
+        else if constexpr (C == 64) b.w[0] = W[1];
+        else {
+            b.w[0] = W[2];
+            b.w[1] = W[3];
+        }
+        return b;
+    }
+    // the C bits of plane-0 level that lanes `src` hold
+    template <int C> __device__ __forceinline__ Bits fetch_bits(int src) const
+    {
+        Bits b{{0, 0}};
+        if constexpr (C <= 16) b.w[0] = (uint64_t)((wb_u((uint32_t)A[0], src) >> C) & ((1u << C) - 1u));
+        else if constexpr (C == 32) b.w[0] = (uint64_t)wb_u((uint32_t)(A[0] >> 32), src);
+        else if constexpr (C == 64) b.w[0] = wb_u64(A[1], src);
+        else {
+            b.w[0] = wb_u64(A[2], src);
+            b.w[1] = wb_u64(A[3], src);
+        }
+        return b;
+    }
+    // store the 2C bits (xl ^ xr, xr) of a node whose children have C bits per lane
+    template <int C> static __device__ __forceinline__ void put_pair(uint64_t *W, bool root, const Bits &xl, const Bits &xr)
+    {
+        if constexpr (C <= 16) {
+            const uint64_t x = (xl.w[0] ^ xr.w[0]) | (xr.w[0] << C);
+            if (root) W[0] = x;
+            else {
+                const uint64_t m = ((((uint64_t)1) << (2 * C)) - 1) << (2 * C);
+                W[0] = (W[0] & ~m) | (x << (2 * C));
+            }
+        } else if constexpr (C == 32) {
+            const uint64_t x = (xl.w[0] ^ xr.w[0]) | (xr.w[0] << 32);
+            if (root) W[0] = x;
+            else W[1] = x;
+        } else if constexpr (C == 64) {
+            W[root ? 0 : 2] = xl.w[0] ^ xr.w[0];
+            W[root ? 1 : 3] = xr.w[0];
+        } else {  // 128 bits per child: the root of N = 512
+            W[0] = xl.w[0] ^ xr.w[0];
+            W[1] = xl.w[1] ^ xr.w[1];
+            W[2] = xr.w[0];
+            W[3] = xr.w[1];
+        }
+    }
+
+    // ---- f / g steps, level LEV -> LEV - 1 (2 <= LEV <= NLOG): c results per lane -------------------------------
+    template <int LEV> __device__ __forceinline__ void step_f()
+    {
+        constexpr int c = 1 << (LEV - 2);
+        constexpr bool MEM = LEV == NLOG || LEV >= 7 || LEV == St::LDS_LEVEL;
+        constexpr int BT = !MEM ? 1 : c < 16 ? c : 16;
+        const int lq = opaque(lane);
+#pragma unroll
+        for (int j0 = 0; j0 < c; j0 += BT) {
+            float a[BT], b[BT];
+#pragma unroll
+            for (int t = 0; t < BT; t++) {
+                if constexpr (LEV == NLOG) {
+                    a[t] = chs[j0 + t];
+                    b[t] = chs[j0 + t + c];
+                } else {
+                    a[t] = ld_own<LEV>(j0 + t, lq);
+                    b[t] = ld_own<LEV>(c + j0 + t, lq);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < BT; t++) st_own<LEV - 1>(j0 + t, f_fast(a[t], b[t]), lq);
+        }
+        level_written<LEV - 1>();
+        own_set<LEV - 1>(oL, (uint32_t)p);
+    }
+    template <int LEV> __device__ __forceinline__ void step_g()
+    {
+        constexpr int c = 1 << (LEV - 2);
+        constexpr bool MEM = LEV == NLOG || LEV >= 7 || LEV == St::LDS_LEVEL;
+        constexpr int BT = MEM ? (c < 16 ? c : 16) : (c < 4 ? c : 4);
+        const int lq = opaque(lane);
+        const int srcP = (int)own_get<LEV - 1>(oP) * 2 + h;
+        const int srcL = opaque((LEV == NLOG) ? 0 : (int)own_get<(LEV == NLOG ? 1 : LEV)>(oL) * 2 + h);
+        const Bits bits = fetch_bits<c>(srcP);
+#pragma unroll
+        for (int j0 = 0; j0 < c; j0 += BT) {
+            float a[BT], b[BT];
+#pragma unroll
+            for (int t = 0; t < BT; t++) {
+                if constexpr (LEV == NLOG) {
+                    a[t] = chs[j0 + t];
+                    b[t] = chs[j0 + t + c];
+                } else {
+                    a[t] = ld_from<LEV>(j0 + t, srcL);
+                    b[t] = ld_from<LEV>(c + j0 + t, srcL);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < BT; t++) {
+                const int j = j0 + t;
+                st_own<LEV - 1>(j, g_fast(a[t], b[t], (uint32_t)(bits.w[j >> 6] >> (j & 63)) & 1u), lq);
+            }
+        }
+        level_written<LEV - 1>();
+        own_set<LEV - 1>(oL, (uint32_t)p);
+    }
+    template <int LEV> __device__ __forceinline__ void combine(int plane)
+    {
+        constexpr int C = 1 << (LEV - 2);  // bits per lane of each child
+        const int srcP = (int)own_get<LEV - 1>(oP) * 2 + h;
+        const Bits xl = fetch_bits<C>(srcP);
+        const Bits xr = get_bits<C>(Bp);
+        if constexpr (LEV == NLOG) {
+            put_pair<C>(Rt, true, xl, xr);
+        } else if (plane) {
+            put_pair<C>(Bp, false, xl, xr);
+        } else {
+            put_pair<C>(A, false, xl, xr);
+            own_set<LEV>(oP, (uint32_t)p);
+        }
+    }
+
+    // ---- fork / prune -------------------------------------------------------------------------------------------
+    // my position becomes the continuation u = b of the path in position par (cpm: every lane's candidate metric);
+    // WITH_X: the first leaf of a 2-leaf node, whose LLRs travel with the path
+    template <bool WITH_X> __device__ __forceinline__ void take_over(float cpm, int par, uint32_t b)
+    {
+        const int src = par * 2 + h;
+        pm = wb_f(cpm, par * 2 + (int)b);
+        oL[0] = wb_u(oL[0], src);
+        oL[1] = wb_u(oL[1], src);
+        oP[0] = wb_u(oP[0], src);
+        oP[1] = wb_u(oP[1], src);
+        if (WITH_X) x = wb_f(x, src);
+    }
+
+    // One leaf; v = its decision LLR (the same in both lanes of a path).  Returns the bit of the path that holds
+    // this position afterwards.  keys: 64 words of LDS, inv: 32 words.
+    template <bool WITH_X> __device__ __forceinline__ uint32_t leaf(float v, uint32_t is_info, uint32_t *keys, uint32_t *inv)
+    {
+        if (!is_info) {
+            pm += wide_metric(v, 0u);
+            return 0u;
+        }
+        const float cpm = pm + wide_metric(v, (uint32_t)h);
+        if (2 * Lcur <= LMAX) {  // list = originals ++ copies
+            const bool is_copy = p >= Lcur && p < 2 * Lcur;
+            const int par = is_copy ? p - Lcur : p;
+            const uint32_t b = is_copy ? 1u : 0u;
+            Lcur *= 2;
+            take_over<WITH_X>(cpm, par, b);
+            return b;
+        }
+        const bool alive = LMAX == 32 || p < LMAX;
+        const uint32_t key = alive ? order_key(cpm) : 0u;  // below the key of -inf
+        const int mypos = h ? p : 32 + p;                  // copies (u = 1) come first in the candidate order
+        keys[mypos] = key;
+        if (lane < LMAX) inv[lane] = 0xFFFFFFFFu;
+        wave_sync();
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < 64; i += 4) {
+            const uint4 k4 = *reinterpret_cast<const uint4 *>(keys + i);
+            cnt += (k4.x > key) ? 1 : 0;
+            cnt += (k4.y > key) ? 1 : 0;
+            cnt += (k4.z > key) ? 1 : 0;
+            cnt += (k4.w > key) ? 1 : 0;
+        }
+        if (cnt < LMAX) inv[cnt] = (uint32_t)lane;
+        wave_sync();
+        uint32_t win = inv[p < LMAX ? p : 0];
+        const uint64_t claimed = __ballot(cnt < LMAX);
+        const uint64_t empty = __ballot(alive && win == 0xFFFFFFFFu);
+        if (__popcll(claimed) != LMAX || empty != 0) {
+            // equal metrics among the candidates that matter: the exact order, with the position as second key
+            wave_sync();
+            if (lane < LMAX) inv[lane] = 0xFFFFFFFFu;
+            wave_sync();
+            cnt = 0;
+#pragma unroll 4
+            for (int i = 0; i < 64; i++) {
+                const uint32_t k = keys[i];
+                cnt += (k > key || (k == key && i < mypos)) ? 1 : 0;
+            }
+            if (cnt < LMAX) inv[cnt] = (uint32_t)lane;
+            wave_sync();
+            win = inv[p < LMAX ? p : 0];
+        }
+        wave_sync();
+        const uint32_t b = win & 1u;
+        const int par = (int)(win >> 1);
+        if (__ballot(alive && par != p) == 0) {  // nothing moves between positions
+            const float other = swap2(cpm);
+            pm = (b == (uint32_t)h) ? cpm : other;
+            return b;
+        }
+        take_over<WITH_X>(cpm, par, b);
+        return b;
+    }
+
+    // A 2-leaf node; xin = my element of its LLRs, m2 = its rate profile.  Returns my element of its partial sums.
+    __device__ __forceinline__ uint32_t node2(float xin, uint32_t m2, uint32_t *keys, uint32_t *inv)
+    {
+        x = xin;
+        const float v0 = f_fast(x, swap2(x));
+        const uint32_t u0 = leaf<true>(v0, m2 & 1u, keys, inv);
+        oL[1] = (oL[1] & 0x7FFFFFFFu) | (u0 << 31);  // travels with the path through the forks of the second leaf
+        const float t = h ? x : flip_sign(x, u0);
+        const float v1 = t + swap2(t);
+        const uint32_t u1 = leaf<false>(v1, (m2 >> 1) & 1u, keys, inv);
+        const uint32_t u0_now = oL[1] >> 31;
+        return h ? u1 : (u0_now ^ u1);
+    }
+};
+
+template <int LEV, int NLOG, int LMAX>
+__device__ __forceinline__ void wide_node(WideDec<NLOG, LMAX> &d, uint32_t maskv, uint32_t idx, int plane, uint32_t *keys, uint32_t *inv)
+{
+#pragma nounroll
+    for (uint32_t hh = 0; hh < 2; hh++) {
+        if (hh == 0) d.template step_f<LEV>();
+        else d.template step_g<LEV>();
+        const uint32_t cidx = 2 * idx + hh;
+        if constexpr (LEV == 2) {
+            const uint32_t mw = (uint32_t)__builtin_amdgcn_readlane((int)maskv, (int)(cidx >> 4));
+            const uint32_t m2 = (mw >> (2 * (cidx & 15))) & 3u;
+            const uint32_t xb = d.node2(d.R[1], m2, keys, inv);
+            if (hh) {
+                d.Bp[0] = (d.Bp[0] & ~(uint64_t)2) | ((uint64_t)xb << 1);
+            } else {
+                d.A[0] = (d.A[0] & ~(uint64_t)2) | ((uint64_t)xb << 1);
+                WideDec<NLOG, LMAX>::template own_set<1>(d.oP, (uint32_t)d.p);
+            }
+        } else {
+            wide_node<LEV - 1, NLOG, LMAX>(d, maskv, cidx, (int)hh, keys, inv);
+        }
+    }
+    d.template combine<LEV>(plane);
+}
+
+// 16 bits spread to the even bit positions of a word
+__device__ __forceinline__ uint32_t spread16(uint32_t v)
+{
+    v = (v | (v << 8)) & 0x00FF00FFu;
+    v = (v | (v << 4)) & 0x0F0F0F0Fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+
+template <int NLOG, int LMAX>
+__global__ void __launch_bounds__(64, 3) scl_wide_kernel(const float *__restrict__ llr, const uint32_t *__restrict__ maskw,
+                                                        const uint32_t *__restrict__ Apos, uint32_t *__restrict__ info_hat, int64_t B,
+                                                        int K, int Kw, float *__restrict__ slab)
+{
+    constexpr int N = 1 << NLOG;
+    constexpr int NW = N / 32;
+    __shared__ __attribute__((aligned(16))) float chan_s[N];  // [parity][N/2]; the output stage reuses it for bit words
+    __shared__ __attribute__((aligned(16))) uint32_t keys[64];
+    __shared__ uint32_t inv[32];
+    __shared__ float lvl6_s[WideStore<NLOG>::LDS_VALUES];
+    using Dec = WideDec<NLOG, LMAX>;
+    Dec d;
+    d.lane = threadIdx.x;
+    d.p = d.lane >> 1;
+    d.h = d.lane & 1;
+    d.memu = slab + (size_t)blockIdx.x * (WideStore<NLOG>::MEM_ROWS > 0 ? WideStore<NLOG>::MEM_ROWS : 1) * 64;
+    d.chs = chan_s + d.h * (N / 2);
+    d.lds6u = lvl6_s;
+    const uint32_t maskv = maskw[(d.lane & 31) < NW ? (d.lane & 31) : 0];
+
+    for (int64_t f = blockIdx.x; f < B; f += gridDim.x) {
+        // channel LLRs of the frame: coalesced 16-byte loads, stored split by parity (element 2j + h at [h][j])
+        const float4 *src = reinterpret_cast<const float4 *>(llr + f * N);
+#pragma unroll
+        for (int t = d.lane; t < N / 4; t += 64) {
+            const float4 v = src[t];
+            *reinterpret_cast<float2 *>(chan_s + 2 * t) = make_float2(v.x, v.z);
+            *reinterpret_cast<float2 *>(chan_s + N / 2 + 2 * t) = make_float2(v.y, v.w);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) d.A[i] = d.Bp[i] = d.Rt[i] = 0;
+        d.pm = 0.0f;
+        d.oL[0] = d.oL[1] = d.oP[0] = d.oP[1] = 0u;
+        d.x = 0.0f;
+        d.Lcur = 1;
+        wave_sync();
+        wide_node<NLOG, NLOG, LMAX>(d, maskv, 0u, 0, keys, inv);
+
+        // the best path: first of the stable descending order of the list
+        const bool act = d.p < d.Lcur;
+        const uint32_t key = (act && d.h == 0) ? order_key(d.pm) : 0u;
+        keys[d.h ? 32 + d.p : d.p] = key;
+        wave_sync();
+        int rank = 0;
+#pragma unroll 4
+        for (int q = 0; q < 32; q++) {
+            const uint32_t k = keys[q];
+            rank += (k > key || (k == key && q < d.p)) ? 1 : 0;
+        }
+        wave_sync();
+        // its root partial sums (x_hat, lane h holds elements 2j + h) as natural-order words in LDS
+        uint32_t *bw = reinterpret_cast<uint32_t *>(chan_s);  // [2][8] lane streams, then NW words of x_hat / u_hat at +32
+        if (act && rank == 0 && d.h == 0) inv[0] = (uint32_t)d.p;
+        wave_sync();
+        const int best = (int)inv[0];
+        if (d.p == best) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                bw[d.h * 8 + 2 * i] = (uint32_t)d.Rt[i];
+                bw[d.h * 8 + 2 * i + 1] = (uint32_t)(d.Rt[i] >> 32);
+            }
+        }
+        wave_sync();
+        uint32_t *uw = bw + 32;
+        if (d.lane < NW) {
+            const int w = d.lane;
+            const uint32_t s0 = (bw[w >> 1] >> (16 * (w & 1))) & 0xFFFFu, s1 = (bw[8 + (w >> 1)] >> (16 * (w & 1))) & 0xFFFFu;
+            uw[w] = butterfly_word(spread16(s0) | (spread16(s1) << 1), NLOG);
+        }
+        for (int s = 5; s < NLOG; s++) {
+            wave_sync();
+            const int dd = 1 << (s - 5);
+            if (d.lane < NW && !(d.lane & dd)) uw[d.lane] ^= uw[d.lane + dd];
+        }
+        wave_sync();
+        uint32_t *dst = info_hat + f * Kw;
+        pack_bits_group<64>(
+            K, d.lane, 0,
+            [&](int k) {
+                const uint32_t pos = Apos[k];
+                return ((uw[pos >> 5] >> (pos & 31)) & 1u) != 0u;
+            },
+            [&](int wi, uint32_t v) {
+                if (d.lane == 0) dst[wi] = v;
+            });
+        if (K == 0 && d.lane == 0) dst[0] = 0u;
+        wave_sync();
+    }
+}
+
+template <int NLOG, int LMAX> int launch_wide_t(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B)
+{
+    polar_ctx *ctx = c->ctx;
+    auto kern = scl_wide_kernel<NLOG, LMAX>;
+    int occ = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, 0));
+    if (occ < 1) occ = 1;
+    const int64_t grid = std::min<int64_t>(B, (int64_t)ctx->num_cus * occ);
+    int rc;
+    if ((rc = ctx->scl_slab.reserve(std::max<size_t>(4, (size_t)grid * WideStore<NLOG>::MEM_ROWS * 64 * sizeof(float))))) return rc;
+    LaunchTimer tm(ctx);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), 0, ctx->stream, (const float *)llr, (const uint32_t *)c->d_maskw,
+                       (const uint32_t *)c->d_A, info_hat, B, c->K, c->Kw, ctx->scl_slab.as<float>());
+    HIP_TRY(hipGetLastError());
+    const float ms = tm.stop();
+    snprintf(c->last.kernel, sizeof(c->last.kernel), "scl_wide_kernel<%d>/L%d", NLOG, LMAX);
+    c->last.lanes_per_frame = 64;
+    c->last.lds_bytes_per_block = 4 * c->N + 384 + 4 * WideStore<NLOG>::LDS_VALUES;
+    c->last.block_threads = 64;
+    c->last.grid_blocks = (int)grid;
+    c->last.last_ms = ms;
+    return POLAR_OK;
+}
+
+template <int NLOG> int launch_wide_l(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, int L)
+{
+    if (L == 32) return launch_wide_t<NLOG, 32>(c, llr, info_hat, B);
+    return launch_wide_t<NLOG, 16>(c, llr, info_hat, B);
+}
+
+}  // namespace
+
+bool scl_wide_supported(const polar_code *c, int dtype, int L, const void *pm, const void *u_hat_all, bool crc, const void *truth)
+{
+    if (dtype != POLAR_F32 || (L != 16 && L != 32) || pm || u_hat_all || crc || truth) return false;
+    if (c->n < 6 || c->n > 9 || c->K < 5) return false;
+    const char *e = getenv("POLAR_SCL_KERNEL");
+    if (e && e[0] == 'l') return false;  // "lds": force the LDS-staged kernel
+    return true;
+}
+
+int launch_scl_wide(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, int L)
+{
+    if (B == 0) return POLAR_OK;
+    switch (c->n) {
+    case 6: return launch_wide_l<6>(c, llr, info_hat, B, L);
+    case 7: return launch_wide_l<7>(c, llr, info_hat, B, L);
+    case 8: return launch_wide_l<8>(c, llr, info_hat, B, L);
+    case 9: return launch_wide_l<9>(c, llr, info_hat, B, L);
+    default: polar_set_error("wide list kernel: unsupported length"); return POLAR_EUNSUPPORTED;
+    }
+}

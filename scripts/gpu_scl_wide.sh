@@ -1,0 +1,21 @@
+# list decoding with 16 / 32 paths: the two-lanes-per-path register kernel against the LDS-staged kernel
+R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
+for V in reg lds; do
+POLAR_SCL_KERNEL=$V timeout -k 10 300 python3 - <<'PY' || exit 1
+import sys, os; sys.path[:0]=['polar-codes_amd','.']
+import numpy as np, torch, _native, functions as pcf
+from channel import Channel
+ctx=_native.default_ctx(0); ctx.enable_timing(True)
+for (cons,N,K,L,snr,nb) in [('rmpolar',512,256,32,2.0,1<<17),('dega',512,256,32,2.0,1<<17),('dega',512,256,16,2.0,1<<17),('dega',256,128,32,2.0,1<<17),('dega',128,64,32,2.0,1<<17)]:
+    if os.environ['POLAR_SCL_KERNEL']=='lds': nb >>= 2
+    mask = pcf.degaBuild(N,K,2.0) if cons=='dega' else pcf.rmPolarBuild(N,K,2.0)
+    code=_native.Code(ctx,mask); n0=Channel('BPSK',snr,'SNRb',K/N).noisePower
+    llr=torch.empty((nb,N),dtype=torch.float32,device='cuda'); info=torch.empty((nb,code.Kw),dtype=torch.int32,device='cuda'); hat=torch.empty_like(info)
+    code.gen_frames_dev(info.data_ptr(),llr.data_ptr(),np.float32,n0,1,0,nb)
+    ms=[]
+    for _ in range(3):
+        code.scl_decode_dev(llr.data_ptr(),np.float32,L,hat.data_ptr(),nb); ms.append(code.last_launch()['last_ms'])
+    li=code.last_launch(); cnt=torch.zeros(3,dtype=torch.int64,device='cuda'); code.count_errors_dev(info.data_ptr(),hat.data_ptr(),nb,cnt.data_ptr()); ctx.sync()
+    print(os.environ.get('POLAR_SCL_KERNEL'),cons,N,K,L,snr,'Mframes/s %.3f'%(nb/(min(ms)*1e-3)/1e6),'ms %.2f'%min(ms),'fer %.5f'%(cnt[1].item()/nb), li['kernel'], 'grid',li['grid_blocks'], flush=True)
+PY
+done

@@ -188,3 +188,27 @@ def test_scl8_headline_kernel_vs_fp32_oracle(monkeypatch, snr):
     assert err < 1e-5
     assert same[~inside].all(), np.flatnonzero(~same & ~inside)[:10]
     assert (~same).sum() <= 0.01 * B
+
+
+@pytest.mark.parametrize("L", [32, 16])
+@pytest.mark.parametrize("cons,N,K", [("dega", 64, 32), ("dega", 128, 64), ("dega", 256, 128), ("dega", 512, 256), ("rmpolar", 512, 256),
+                                      ("dega", 512, 150), ("dega", 256, 200)])
+def test_scl_wide_kernel_equals_lds_kernel(monkeypatch, cons, N, K, L):
+    """The two-lanes-per-path register kernel for lists of 16 and 32 paths against the LDS-staged kernel, which runs the
+    same fp32 arithmetic in the same order: identical decoded bits, frame by frame, at an SNR with plenty of close
+    decisions (and, at the short lengths, exactly tied metrics)."""
+    mask = pcf.degaBuild(N, K, 2.0) if cons == "dega" else pcf.rmPolarBuild(N, K, 2.0)
+    code = _native.Code(_native.default_ctx(), mask)
+    rs = np.random.RandomState(N + K + L)
+    B = 1201
+    x = oracle.polar_encode(rs.randint(0, 2, size=(B, K)), mask).reshape(B, N)
+    n0 = 1.0 / (K / N * 10 ** (1.0 / 10))
+    llr = code.channel_llr(x, n0, 13, 0, np.float32)
+    llr[:40] = np.round(llr[:40])  # integer LLRs: equal candidate metrics happen
+    monkeypatch.delenv("POLAR_SCL_KERNEL", raising=False)
+    a, _, _ = code.scl_decode(llr, L)
+    assert code.last_launch()["kernel"].startswith("scl_wide_kernel"), code.last_launch()
+    monkeypatch.setenv("POLAR_SCL_KERNEL", "lds")
+    b, _, _ = code.scl_decode(llr, L)
+    assert code.last_launch()["kernel"].startswith("scl_decode_kernel")
+    assert np.array_equal(a, b), np.flatnonzero(np.any(a != b, axis=1))[:20]
