@@ -129,27 +129,35 @@ template <int NLOG> struct SclStore {
 template <int NLOG, int LMAX = 8> struct SclReg {
     static constexpr int S = SclStore<NLOG>::REG_VALUES;
     float R[S];           // level l (3 <= l < NLOG) kept in registers: 2^(l-3) values at offset 2^(l-3)
-    float *lv_lds;        // the LDS level of this wavefront, + my lane
-    float *lv_glb;        // the global level of this wavefront, + my lane
+    float *lv_lds;        // the LDS level of this wavefront (wave-uniform)
+    float *lv_glb;        // the global level of this wavefront (wave-uniform)
     int my_lane;
 
-    // element j of my level L / of the level-L values that the lanes `src` (owner position * 8 + q) hold / store
-    template <int L> __device__ __forceinline__ float ld_own(int j) const
+    // element j of my level L / of the level-L values that the lanes `src` (owner position * 8 + q) hold / store.
+    // Accesses to the levels in memory take the lane number through an opaque copy made inside the step (`lq`): their
+    // addresses are then formed there, base plus instruction offset, instead of being hoisted out of the frame loop
+    // as one 64-bit register pair per row.
+    static __device__ __forceinline__ int opaque(int v)
     {
-        if constexpr (L == SclStore<NLOG>::GLOBAL_LEVEL) return lv_glb[j * 64];
-        else if constexpr (L == SclStore<NLOG>::LDS_LEVEL) return lv_lds[j * 64];
+        asm volatile("" : "+v"(v));
+        return v;
+    }
+    template <int L> __device__ __forceinline__ float ld_own(int j, int lq) const
+    {
+        if constexpr (L == SclStore<NLOG>::GLOBAL_LEVEL) return lv_glb[j * 64 + lq];
+        else if constexpr (L == SclStore<NLOG>::LDS_LEVEL) return lv_lds[j * 64 + lq];
         else return R[(1 << (L - 3)) + j];
     }
     template <int L> __device__ __forceinline__ float ld_from(int j, int src) const
     {
-        if constexpr (L == SclStore<NLOG>::GLOBAL_LEVEL) return lv_glb[j * 64 + (src - my_lane)];
-        else if constexpr (L == SclStore<NLOG>::LDS_LEVEL) return lv_lds[j * 64 + (src - my_lane)];
+        if constexpr (L == SclStore<NLOG>::GLOBAL_LEVEL) return lv_glb[j * 64 + src];
+        else if constexpr (L == SclStore<NLOG>::LDS_LEVEL) return lv_lds[j * 64 + src];
         else return bperm_f(R[(1 << (L - 3)) + j], src);
     }
-    template <int L> __device__ __forceinline__ void st_own(int j, float v)
+    template <int L> __device__ __forceinline__ void st_own(int j, float v, int lq)
     {
-        if constexpr (L == SclStore<NLOG>::GLOBAL_LEVEL) lv_glb[j * 64] = v;
-        else if constexpr (L == SclStore<NLOG>::LDS_LEVEL) lv_lds[j * 64] = v;
+        if constexpr (L == SclStore<NLOG>::GLOBAL_LEVEL) lv_glb[j * 64 + lq] = v;
+        else if constexpr (L == SclStore<NLOG>::LDS_LEVEL) lv_lds[j * 64 + lq] = v;
         else R[(1 << (L - 3)) + j] = v;
     }
     // after a level held in memory was written and before other lanes read it
@@ -199,6 +207,7 @@ template <int NLOG, int LMAX = 8> struct SclReg {
         constexpr int c = 1 << (LEV - 4);
         constexpr bool MEM = LEV == NLOG || LEV == SclStore<NLOG>::GLOBAL_LEVEL || LEV == SclStore<NLOG>::LDS_LEVEL;
         constexpr int BT = !MEM ? 1 : c < 16 ? c : 16;
+        const int lq = opaque(my_lane);
 #pragma unroll
         for (int j0 = 0; j0 < c; j0 += BT) {
             float a[BT], b[BT];
@@ -208,12 +217,12 @@ template <int NLOG, int LMAX = 8> struct SclReg {
                     a[t] = chan_lane[8 * (j0 + t)];
                     b[t] = chan_lane[8 * (j0 + t + c)];
                 } else {
-                    a[t] = ld_own<LEV>(j0 + t);
-                    b[t] = ld_own<LEV>(c + j0 + t);
+                    a[t] = ld_own<LEV>(j0 + t, lq);
+                    b[t] = ld_own<LEV>(c + j0 + t, lq);
                 }
             }
 #pragma unroll
-            for (int t = 0; t < BT; t++) st_own<LEV - 1>(j0 + t, f_fast(a[t], b[t]));
+            for (int t = 0; t < BT; t++) st_own<LEV - 1>(j0 + t, f_fast(a[t], b[t]), lq);
         }
         level_written<LEV - 1>();
         st.ownL = own_set(st.ownL, LEV - 1, (uint32_t)lc.p);
@@ -225,7 +234,8 @@ template <int NLOG, int LMAX = 8> struct SclReg {
         constexpr bool MEM = LEV == NLOG || LEV == SclStore<NLOG>::GLOBAL_LEVEL || LEV == SclStore<NLOG>::LDS_LEVEL;
         constexpr int BT = MEM ? (c < 16 ? c : 16) : (c < 4 ? c : 4);  // register levels: four pairs of lane gathers in flight
         const int srcP = (int)own_get(st.ownP, LEV - 1) * 8 + lc.q;
-        const int srcL = (LEV == NLOG) ? 0 : (int)own_get(st.ownL, LEV) * 8 + lc.q;
+        const int srcL = opaque((LEV == NLOG) ? 0 : (int)own_get(st.ownL, LEV) * 8 + lc.q);
+        const int lq = opaque(my_lane);
         uint64_t bits;
         if constexpr (c == 64) bits = bperm_u64(a1, srcP);
         else if constexpr (c >= 16) bits = (bperm_u64(a0, srcP) >> c) & (((uint64_t)1 << c) - 1);
@@ -245,7 +255,7 @@ template <int NLOG, int LMAX = 8> struct SclReg {
                 }
             }
 #pragma unroll
-            for (int t = 0; t < BT; t++) st_own<LEV - 1>(j0 + t, g_fast(a[t], b[t], (uint32_t)(bits >> (j0 + t)) & 1u));
+            for (int t = 0; t < BT; t++) st_own<LEV - 1>(j0 + t, g_fast(a[t], b[t], (uint32_t)(bits >> (j0 + t)) & 1u), lq);
         }
         level_written<LEV - 1>();
         st.ownL = own_set(st.ownL, LEV - 1, (uint32_t)lc.p);
@@ -547,7 +557,7 @@ __device__ __forceinline__ void scl_node(SclReg<NLOG, LMAX> &d, uint32_t maskv, 
 }
 
 template <int NLOG, int LMAX>
-__global__ void __launch_bounds__(64, NLOG == 10 ? 3 : 4) scl_reg_kernel(const float *__restrict__ llr, const uint32_t *__restrict__ maskw,
+__global__ void __launch_bounds__(64, 4) scl_reg_kernel(const float *__restrict__ llr, const uint32_t *__restrict__ maskw,
                                                         const uint16_t *__restrict__ Asl8, const uint32_t *__restrict__ crcS,
                                                         const uint32_t *__restrict__ truth, uint32_t *__restrict__ info_hat, int64_t B,
                                                         int K, int Kw, float *__restrict__ slab)
@@ -559,10 +569,15 @@ __global__ void __launch_bounds__(64, NLOG == 10 ? 3 : 4) scl_reg_kernel(const f
     uint32_t *const stage = xchg;
     uint32_t *const passw = xchg + 320;  // bitmap of the list entries that pass the CRC / equal the transmitted word
     constexpr int N = 1 << NLOG;
-    __shared__ uint16_t asl_s[N];       // the gather table of the output stage (the CRC remainders stay in global memory)
+    // the gather table of the output stage (the CRC remainders stay in global memory); at N = 1024, where LDS decides how
+    // many wavefronts a CU holds, it is read from global memory instead
+    constexpr bool ASL_LDS = NLOG < 10;
+    __shared__ uint16_t asl_s[ASL_LDS ? N : 1];
     __shared__ float lvl_s[SclStore<NLOG>::LDS_VALUES];
-    for (int k = threadIdx.x; k < K; k += 64) asl_s[k] = Asl8[k];
-    wave_sync();
+    if constexpr (ASL_LDS) {
+        for (int k = threadIdx.x; k < K; k += 64) asl_s[k] = Asl8[k];
+        wave_sync();
+    }
     LaneConst lc;
     lc.lane = threadIdx.x;
     lc.p = lc.lane >> 3;
@@ -590,8 +605,8 @@ __global__ void __launch_bounds__(64, NLOG == 10 ? 3 : 4) scl_reg_kernel(const f
     const uint32_t maskv = maskw[(lc.lane & 31) < (N / 32) ? (lc.lane & 31) : 0];
     SclReg<NLOG, LMAX> d;
     d.my_lane = lc.lane;
-    d.lv_lds = lvl_s + lc.lane;
-    d.lv_glb = slab + (size_t)blockIdx.x * SclStore<NLOG>::GLOBAL_VALUES + lc.lane;
+    d.lv_lds = lvl_s;
+    d.lv_glb = slab + (size_t)blockIdx.x * SclStore<NLOG>::GLOBAL_VALUES;
 
     for (int64_t f = blockIdx.x; f < B; f += gridDim.x) {
         const float *chan_lane = llr + f * N + lc.e;
@@ -642,7 +657,7 @@ __global__ void __launch_bounds__(64, NLOG == 10 ? 3 : 4) scl_reg_kernel(const f
             pack_bits_group<8>(
                 K, lc.q, lc.p,
                 [&](int k) {
-                    const uint32_t a = asl_s[k];  // (lane-in-path << 7) | bit
+                    const uint32_t a = ASL_LDS ? asl_s[k] : Asl8[k];  // (lane-in-path << 7) | bit
                     const bool bit = ((mine[(a >> 7) * 4 + ((a >> 5) & 3u)] >> (a & 31u)) & 1u) != 0u;
                     if (crcS && bit) syn ^= crcS[k];
                     return bit;
@@ -742,7 +757,7 @@ static int launch_scl_reg_t(polar_code *c, const void *llr, uint32_t *info_hat, 
     float ms = tm.stop();
     snprintf(c->last.kernel, sizeof(c->last.kernel), "scl_reg_kernel<%d>/L%d", NLOG, LMAX);
     c->last.lanes_per_frame = 64;
-    c->last.lds_bytes_per_block = 32 + 1024 + 2 * c->N + 4 * SclStore<NLOG>::LDS_VALUES;
+    c->last.lds_bytes_per_block = 1536 + (NLOG < 10 ? 2 * c->N : 2) + 4 * SclStore<NLOG>::LDS_VALUES;
     c->last.block_threads = 64;
     c->last.grid_blocks = (int)grid;
     c->last.last_ms = ms;
