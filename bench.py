@@ -25,10 +25,9 @@ for p in (ROOT, os.path.join(ROOT, "polar-codes_amd")):
 import numpy as np
 
 # Peaks from the MI355X micro-architecture guide: HBM3E 8 TB/s; vector ALU 256 CUs x 4 SIMD x 32 lanes
-# x 2.4 GHz = 78.6 T lane-operations/s; LDS aggregate with every CU streaming ds_read_b64/b128 ~150 TB/s.
+# x 2.4 GHz = 78.6 T lane-operations/s.
 HBM_PEAK_GBS = 8000.0
 VALU_PEAK_TLOPS = 256 * 4 * 32 * 2.4e9 / 1e12
-LDS_PEAK_GBS = 150000.0
 
 
 def measured_traffic(kernel_name, frames):
@@ -43,6 +42,21 @@ def measured_traffic(kernel_name, frames):
         if kernel_name.startswith(k):
             return v * frames
     return None
+
+
+def leg_roofline(kernel, kernel_ms, frames, N, K, paths=1, hbm_bytes_per_frame=None):
+    """Roofline of a secondary leg from the algorithmic counts per frame: vector-ALU lane operations
+    paths x 3.5 N log2 N (f: 4, g: 2, partial-sum xor: 1 per element and level, per path of a list), and HBM bytes
+    4 N in + K/8 out (external-LLR mode; 0 in for the one-kernel Monte-Carlo loop).  Kernel time from the HIP events
+    on the launch stream; `traffic` from the PMC passes on file for this kernel, if any."""
+    ops = paths * 3.5 * N * np.log2(N)
+    byts = (4 * N + K / 8) if hbm_bytes_per_frame is None else hbm_bytes_per_frame
+    secs = kernel_ms * 1e-3
+    return {"bound": "valu", "achieved": ops * frames / secs / 1e12, "peak": VALU_PEAK_TLOPS, "unit": "Tlane-op/s",
+            "frac": ops * frames / secs / 1e12 / VALU_PEAK_TLOPS, "traffic": measured_traffic(kernel, frames),
+            "algorithmic_lane_ops_per_frame": ops, "algorithmic_bytes_per_frame": byts,
+            "hbm_GBs_algorithmic": byts * frames / secs / 1e9, "hbm_frac": byts * frames / secs / 1e9 / HBM_PEAK_GBS,
+            "kernel": kernel, "kernel_ms": kernel_ms}
 
 
 def lds_bytes_algorithmic(N):
@@ -277,15 +291,6 @@ def main():
                 "frac": 3.5 * N * np.log2(N) * B / (k_ms * 1e-3) / 1e12 / VALU_PEAK_TLOPS,
                 "algorithmic_lane_ops_per_frame": 3.5 * N * np.log2(N),
             },
-            "roofline_lds": {
-                "bound": "lds",
-                "achieved": alg_lds / (k_ms * 1e-3) / 1e9,
-                "peak": LDS_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": alg_lds / (k_ms * 1e-3) / 1e9 / LDS_PEAK_GBS,
-                "algorithmic_bytes_per_frame": lds_bytes_algorithmic(N),
-                "note": "on-chip traffic plain SC would move through LDS; the register-resident kernel keeps it in VGPRs",
-            },
         }
 
     if rank == 0 and world == 1 and not a.no_extras:
@@ -308,7 +313,8 @@ def main():
             ctx.sync()
             c2 = c2.cpu().tolist()
             extras["scl8_kernel"] = {"frames_per_s": nb / (li["last_ms"] * 1e-3), "info_mbps": nb * K / (li["last_ms"] * 1e-3) / 1e6,
-                              "kernel": li["kernel"], "kernel_ms": li["last_ms"], "frames": nb, "fer": c2[1] / nb}
+                              "kernel": li["kernel"], "kernel_ms": li["last_ms"], "frames": nb, "fer": c2[1] / nb,
+                              "roofline": leg_roofline(li["kernel"], li["last_ms"], nb, N, K, paths=8)}
         except _native.PolarError as e:
             extras["scl8_kernel"] = {"error": str(e)}
         ctx.enable_timing(False)
@@ -327,14 +333,16 @@ def main():
         try:
             m512 = pcf.rmPolarBuild(512, 256, 2.0)
             c512 = _native.Code(ctx, m512)
-            nb = 1 << 15
+            nb = 1 << 17
             l512 = torch.empty((nb, 512), dtype=torch.float32, device=dev)
             c512.gen_frames_dev(None, l512.data_ptr(), np.float32, ch.noisePower, seed, 0, nb)
             h512 = torch.empty((nb, c512.Kw), dtype=torch.int32, device=dev)
-            c512.scl_decode_dev(l512.data_ptr(), np.float32, 32, h512.data_ptr(), nb)
+            for _ in range(2):
+                c512.scl_decode_dev(l512.data_ptr(), np.float32, 32, h512.data_ptr(), nb)
             li = c512.last_launch()
             extras["scl32_rmpolar_512_256"] = {"frames_per_s": nb / (li["last_ms"] * 1e-3), "kernel": li["kernel"], "kernel_ms": li["last_ms"],
-                                               "frames": nb, "lds_bytes_per_block": li["lds_bytes_per_block"]}
+                                               "frames": nb, "lds_bytes_per_block": li["lds_bytes_per_block"],
+                                               "roofline": leg_roofline(li["kernel"], li["last_ms"], nb, 512, 256, paths=32)}
             del l512, h512
             m16k = pcf.degaBuild(16384, 8192, 2.0)
             c16k = _native.Code(ctx, m16k)
@@ -347,7 +355,8 @@ def main():
             li = c16k.last_launch()
             extras["sc_16384_8192"] = {"frames_per_s": nb / (li["last_ms"] * 1e-3), "info_mbps": nb * 8192 / (li["last_ms"] * 1e-3) / 1e6,
                                        "kernel": li["kernel"], "kernel_ms": li["last_ms"], "frames": nb,
-                                       "lds_bytes_per_block": li["lds_bytes_per_block"]}
+                                       "lds_bytes_per_block": li["lds_bytes_per_block"],
+                                       "roofline": leg_roofline(li["kernel"], li["last_ms"], nb, 16384, 8192)}
             del l16k, h16k
         except _native.PolarError as e:
             extras["other_configs_error"] = str(e)
@@ -388,6 +397,29 @@ def main():
             del ica, hca, lca
         except _native.PolarError as e:
             extras["ca_scl8_1024_512_crc24"] = {"error": str(e)}
+        # the reference's own arithmetic: fp64 SC with every leaf visited (decision LLRs available) and fp64 list decoding
+        # with the whole list returned -- what PolarCode.scDecoder / sclDecoder run by default (bit-exact mode)
+        try:
+            nb = 1 << 16
+            l64 = llr[:nb].double()
+            h64 = torch.empty((nb, code.Kw), dtype=torch.int32, device=dev)
+            for _ in range(2):
+                code.sc_decode_dev(l64.data_ptr(), np.float64, h64.data_ptr(), nb, fast=False)
+            li = code.last_launch()
+            extras["sc_fp64_parity_mode"] = {"frames_per_s": nb / (li["last_ms"] * 1e-3), "info_mbps": nb * K / (li["last_ms"] * 1e-3) / 1e6,
+                                             "kernel": li["kernel"], "kernel_ms": li["last_ms"], "frames": nb,
+                                             "roofline": leg_roofline(li["kernel"], li["last_ms"], nb, N, K, hbm_bytes_per_frame=8 * N + K / 8)}
+            nb = 1 << 14
+            pm64 = torch.empty((nb, 8), dtype=torch.float64, device=dev)
+            for _ in range(2):
+                code.scl_decode_dev(l64.data_ptr(), np.float64, 8, h64.data_ptr(), nb, pm_ptr=pm64.data_ptr())
+            li = code.last_launch()
+            extras["scl8_fp64_parity_mode"] = {"frames_per_s": nb / (li["last_ms"] * 1e-3), "info_mbps": nb * K / (li["last_ms"] * 1e-3) / 1e6,
+                                               "kernel": li["kernel"], "kernel_ms": li["last_ms"], "frames": nb,
+                                               "roofline": leg_roofline(li["kernel"], li["last_ms"], nb, N, K, paths=8, hbm_bytes_per_frame=8 * N + K / 8)}
+            del l64, h64, pm64
+        except _native.PolarError as e:
+            extras["fp64_error"] = str(e)
         ctx.enable_timing(False)
         # the Monte-Carlo loop (draw, encode, channel, decode, count), nothing resident beforehand: as one kernel without an
         # LLR buffer (what polar_mc_run does for a specialised code), and as generator -> buffer -> decoder
@@ -402,6 +434,8 @@ def main():
                 mdt = time.perf_counter() - t0
                 extras[name] = {"frames_per_s": nmc / mdt, "info_mbps": nmc * K / mdt / 1e6, "frames": nmc, "fer": int(mc[1]) / int(mc[0]),
                                 "counters": [int(v) for v in mc], "kernel": code.last_launch()["kernel"]}
+                if not staged:  # the whole loop is one kernel: its roofline from the wall time of the call (no HBM traffic but the counters)
+                    extras[name]["roofline"] = leg_roofline(code.last_launch()["kernel"], mdt * 1e3, nmc, N, K, hbm_bytes_per_frame=0.0)
             finally:
                 os.environ.pop("POLAR_MC_KERNEL", None)
         out["extras"] = extras
