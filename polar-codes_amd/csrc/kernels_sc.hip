@@ -331,6 +331,7 @@ int launch_sc_decode(polar_code *c, const void *llr, int dtype, uint32_t *info_h
 {
     if (B == 0) return POLAR_OK;
     if (sc_reg_supported(c, dtype, u_hat, dec_llr)) return launch_sc_reg(c, llr, dtype, info_hat, B, flags);
+    if (sc_reg_full_supported(c, dtype, u_hat, dec_llr, flags)) return launch_sc_reg_full(c, llr, dtype, info_hat, u_hat, dec_llr, B);
     if (sc_big_supported(c, dtype, u_hat, dec_llr, flags)) return launch_sc_big(c, llr, info_hat, B);
     if (dtype == POLAR_F32) return launch_sc_g<float>(c, llr, info_hat, u_hat, dec_llr, B, flags);
     return launch_sc_g<double>(c, llr, info_hat, u_hat, dec_llr, B, flags);

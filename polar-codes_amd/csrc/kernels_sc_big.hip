@@ -323,6 +323,7 @@ template <int NLOG> static int launch_big_t(polar_code *c, const void *llr, uint
     int occ = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, 0));
     if (occ < 1) occ = 1;
+    if (const char *e = getenv("POLAR_BIG_WAVES")) occ = std::max(1, std::min(occ, atoi(e)));  // experiment: wavefronts per CU
     const int64_t need = (B + 3) / 4;
     const int64_t grid = std::min<int64_t>(need, (int64_t)ctx->num_cus * occ);
     if ((rc = ctx->scl_slab.reserve((size_t)grid * 4 * BigLayout<NLOG>::FRAME_WORDS * 4))) return rc;

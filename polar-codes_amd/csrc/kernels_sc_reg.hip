@@ -65,6 +65,70 @@ __global__ void __launch_bounds__(64, 4) sc_reg_kernel(const T *__restrict__ llr
     if (truth) err_acc_flush(acc, counters);
 }
 
+// The every-leaf walk with the reference's side outputs: u_hat (packed, natural order) and the decision LLRs of all N
+// leaves (self.uHat / self.llrs of scDecoder, cn/polarCode.py:1525-1571), fp32 or fp64.  fp64 is the reference's own
+// arithmetic: f and g only compare, negate, add and subtract, so bits and decision LLRs equal the reference's exactly.
+// Same mapping as sc_reg_kernel; the fp64 slice takes 128 registers per lane, two wavefronts per SIMD.
+template <typename T, int NLOG>
+__global__ void __launch_bounds__(64, sizeof(T) == 8 ? 2 : 4)
+    sc_reg_full_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, const uint16_t *__restrict__ Asl, uint32_t *__restrict__ info_hat,
+                       uint32_t *__restrict__ u_hat, T *__restrict__ dec_llr, int64_t B, int K, int Kw)
+{
+    __shared__ __attribute__((aligned(32))) uint32_t stage[SC_STAGE_WORDS];
+    constexpr int N = 1 << NLOG;
+    constexpr int NW = N / 32;
+    __shared__ uint16_t asl_s[GatherShape<NLOG>::WORDS];
+    for (int k = threadIdx.x; k < GatherShape<NLOG>::WORDS; k += 64) asl_s[k] = Asl[k];
+    wave_sync();
+    const int lane = threadIdx.x;
+    const int grp = lane >> 4;
+    const int sub = lane & 15;
+    RegDec<T, NLOG> d;
+    RowConst rc;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        rc.up[i] = (sub & (8 >> i)) != 0;
+        rc.lowmask[i] = rc.up[i] ? 0u : 0xFFFFFFFFu;
+        rc.low31[i] = rc.up[i] ? 0u : 0x80000000u;
+    }
+    const uint32_t maskv = maskw[(lane & 31) < NW ? (lane & 31) : 0];
+    NodeClasses nc;  // every leaf is visited: no node is short-cut
+#pragma unroll
+    for (int i = 0; i < 7; i++) nc.r0[i] = nc.r1[i] = 0;
+
+    for (int64_t f0 = (int64_t)blockIdx.x * 4; f0 < B; f0 += (int64_t)gridDim.x * 4) {
+        const int64_t f = f0 + grp;
+        const bool active = f < B;
+        const int64_t fc = active ? f : B - 1;  // rows past the end decode the last frame again and store the same values
+        d.ps0 = d.ps1 = 0;
+        d.root = 0;
+        decode_node<NLOG, NLOG, false, RegDec<T, NLOG>, true>(d, nc, maskv, 0u, llr + fc * N + sub, 0u, 0, rc,
+                                                             dec_llr ? dec_llr + fc * N + sub : nullptr, sub);
+        sc_reg_epilogue<NLOG>(d.root, stage, asl_s, info_hat, fc, active, lane, K, Kw);
+        if (u_hat) {
+            // u_hat is staged sliced (element k = bit k / 16 of lane k % 16: its low word at stage[16 l + g], its high word
+            // at stage[16 l + 8 + g]); lane `sub` assembles the natural-order words sub and sub + 16: bit i of word w is
+            // element 32 w + i = bit 2 w + i / 16 of lane i % 16
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const int w = sub + 16 * s;
+                if (w < NW) {
+                    uint32_t v = 0;
+#pragma unroll
+                    for (int l = 0; l < 16; l++) {
+                        const uint32_t sw = stage[16 * l + ((2 * w) >> 5) * 8 + grp];
+                        const uint32_t two = (sw >> ((2 * w) & 31)) & 3u;
+                        v |= (two & 1u) << l;
+                        v |= (two >> 1) << (16 + l);
+                    }
+                    if (active) u_hat[fc * NW + w] = v;
+                }
+            }
+        }
+        wave_sync();
+    }
+}
+
 // ------------------------------------------------------------------------------------------ host side
 // Profile number (1..25) of a 16-leaf rate profile, 0 if it is not one of the compiled ones.
 uint32_t sc_reg_profile_id(uint32_t m16)
@@ -100,10 +164,64 @@ bool sc_reg_supported(const polar_code *c, int dtype, const void *u_hat, const v
     if (u_hat || dec_llr) return false;
     if (c->n < 5 || c->n > 10) return false;
     if (c->K == 0 || c->K == c->N) return false;  // root would be a rate-0 / rate-1 node
-    if (dtype != POLAR_F32) return false;  // fp64 (parity mode) runs on the LDS-staged kernel
+    if (dtype != POLAR_F32) return false;  // fp64 (parity mode) runs on sc_reg_full_kernel or the LDS-staged kernel
     const char *e = getenv("POLAR_SC_KERNEL");
     if (e && e[0] == 'l') return false;  // "lds": force the LDS-staged kernel
     return true;
+}
+
+// every-leaf decoding with u_hat / decision LLRs, and all fp64 decoding, N = 32 .. 1024
+bool sc_reg_full_supported(const polar_code *c, int dtype, const void *u_hat, const void *dec_llr, int flags)
+{
+    if (c->n < 5 || c->n > 10) return false;
+    if (dtype == POLAR_F32 && !u_hat && !dec_llr) return false;  // the fp32 information-bit kernels are faster
+    if ((flags & POLAR_SC_FAST) && dtype == POLAR_F32) return false;
+    const char *e = getenv("POLAR_SC_KERNEL");
+    if (e && e[0] == 'l') return false;
+    return true;
+}
+
+template <typename T, int NLOG> static int launch_full_t(polar_code *c, const void *llr, uint32_t *info_hat, uint32_t *u_hat, void *dec_llr, int64_t B)
+{
+    polar_ctx *ctx = c->ctx;
+    auto kern = sc_reg_full_kernel<T, NLOG>;
+    int occ = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, 0));
+    if (occ < 1) occ = 1;
+    const int64_t need = (B + 3) / 4;
+    const int64_t grid = std::min<int64_t>(need, (int64_t)ctx->num_cus * occ * 8);
+    LaunchTimer tm(ctx);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), 0, ctx->stream, (const T *)llr, (const uint32_t *)c->d_maskw, (const uint16_t *)c->d_Asl,
+                       info_hat, u_hat, (T *)dec_llr, B, c->K, c->Kw);
+    HIP_TRY(hipGetLastError());
+    const float ms = tm.stop();
+    snprintf(c->last.kernel, sizeof(c->last.kernel), "sc_reg_full_kernel<%s,%d>", sizeof(T) == 4 ? "float" : "double", NLOG);
+    c->last.lanes_per_frame = 16;
+    c->last.lds_bytes_per_block = 4 * SC_STAGE_WORDS + 2 * GatherShape<NLOG>::WORDS;
+    c->last.block_threads = 64;
+    c->last.grid_blocks = (int)grid;
+    c->last.last_ms = ms;
+    return POLAR_OK;
+}
+
+template <typename T> static int launch_full_n(polar_code *c, const void *llr, uint32_t *info_hat, uint32_t *u_hat, void *dec_llr, int64_t B)
+{
+    switch (c->n) {
+    case 5: return launch_full_t<T, 5>(c, llr, info_hat, u_hat, dec_llr, B);
+    case 6: return launch_full_t<T, 6>(c, llr, info_hat, u_hat, dec_llr, B);
+    case 7: return launch_full_t<T, 7>(c, llr, info_hat, u_hat, dec_llr, B);
+    case 8: return launch_full_t<T, 8>(c, llr, info_hat, u_hat, dec_llr, B);
+    case 9: return launch_full_t<T, 9>(c, llr, info_hat, u_hat, dec_llr, B);
+    case 10: return launch_full_t<T, 10>(c, llr, info_hat, u_hat, dec_llr, B);
+    default: polar_set_error("register SC kernel: unsupported length"); return POLAR_EUNSUPPORTED;
+    }
+}
+
+int launch_sc_reg_full(polar_code *c, const void *llr, int dtype, uint32_t *info_hat, uint32_t *u_hat, void *dec_llr, int64_t B)
+{
+    if (B == 0) return POLAR_OK;
+    if (dtype == POLAR_F32) return launch_full_n<float>(c, llr, info_hat, u_hat, dec_llr, B);
+    return launch_full_n<double>(c, llr, info_hat, u_hat, dec_llr, B);
 }
 
 template <typename T, int NLOG, bool FAST> static int launch_reg_t(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B)

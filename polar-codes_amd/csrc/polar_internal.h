@@ -129,6 +129,8 @@ int launch_sc_decode(polar_code *c, const void *llr, int dtype, uint32_t *info_h
 uint32_t sc_reg_profile_id(uint32_t m16);
 bool sc_reg_supported(const polar_code *c, int dtype, const void *u_hat, const void *dec_llr);
 int launch_sc_reg(polar_code *c, const void *llr, int dtype, uint32_t *info_hat, int64_t B, int flags);
+bool sc_reg_full_supported(const polar_code *c, int dtype, const void *u_hat, const void *dec_llr, int flags);
+int launch_sc_reg_full(polar_code *c, const void *llr, int dtype, uint32_t *info_hat, uint32_t *u_hat, void *dec_llr, int64_t B);
 bool sc_big_supported(const polar_code *c, int dtype, const void *u_hat, const void *dec_llr, int flags);
 int launch_sc_big(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B);
 void sc_big_release(polar_code *c);

@@ -1,0 +1,18 @@
+# long-code SC kernel at (16384,8192): wavefronts per CU against rate (fewer frames in flight = smaller slab working set)
+R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
+for W in 16 12 8 6 4 3 2; do
+POLAR_BIG_WAVES=$W timeout -k 10 200 python3 - <<'PY' || exit 1
+import sys, os; sys.path[:0]=['polar-codes_amd','.']
+import numpy as np, torch, _native, functions as pcf
+from channel import Channel
+ctx=_native.default_ctx(0); ctx.enable_timing(True)
+N,K,nb=16384,8192,1<<15
+code=_native.Code(ctx,pcf.degaBuild(N,K,2.0)); n0=Channel('BPSK',2.0,'SNRb',K/N).noisePower
+llr=torch.empty((nb,N),dtype=torch.float32,device='cuda'); hat=torch.empty((nb,code.Kw),dtype=torch.int32,device='cuda')
+code.gen_frames_dev(None,llr.data_ptr(),np.float32,n0,1,0,nb)
+ms=[]
+for _ in range(3):
+    code.sc_decode_dev(llr.data_ptr(),np.float32,hat.data_ptr(),nb,fast=True); ms.append(code.last_launch()['last_ms'])
+li=code.last_launch(); print('waves/CU',os.environ['POLAR_BIG_WAVES'],'grid',li['grid_blocks'],'Mframes/s %.2f'%(nb/(min(ms)*1e-3)/1e6),'ms %.2f'%min(ms), 'slab MB %.0f'%(li['grid_blocks']*4*94.2e3/1e6), flush=True)
+PY
+done

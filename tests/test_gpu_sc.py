@@ -51,8 +51,9 @@ def test_sc_fp64_matches_reference_vectors(golden, cons, N, K, snr):
 @pytest.mark.parametrize("lanes", [8, 16, 32, 64])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_sc_every_lane_width_vs_oracle(monkeypatch, lanes, dtype):
-    """All lane-group widths of the kernel, ragged batch sizes, both arithmetic types."""
+    """All lane-group widths of the LDS-staged kernel, ragged batch sizes, both arithmetic types."""
     monkeypatch.setenv("POLAR_SC_LANES", str(lanes))
+    monkeypatch.setenv("POLAR_SC_KERNEL", "lds")
     rs = np.random.RandomState(lanes)
     for N, K in [(64, 20), (256, 128), (1024, 512)]:
         mask = pcf.degaBuild(N, K, 2.0)
@@ -69,6 +70,34 @@ def test_sc_every_lane_width_vs_oracle(monkeypatch, lanes, dtype):
             assert np.array_equal(info[b], oracle.extract(ruh, mask))
         info_f, uh_f, _ = code.sc_decode(llr, want_uhat=True, fast=True)
         assert np.array_equal(uh_f, uh)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_sc_register_kernel_with_side_outputs_vs_oracle(monkeypatch, dtype):
+    """The register-resident every-leaf kernel (u_hat and decision LLRs, fp32 and fp64; what PolarCode.scDecoder runs for
+    N = 32 .. 1024): bits and decision LLRs equal the oracle's exactly, and the LDS-staged kernel's, for every length,
+    extreme rates and batch sizes that do not fill the last wavefront."""
+    rs = np.random.RandomState(5)
+    for N, K in [(32, 16), (64, 0), (64, 64), (128, 100), (256, 3), (512, 256), (1024, 512), (1024, 1023)]:
+        mask = np.zeros(N, dtype=int)
+        mask[np.sort(rs.permutation(N)[:K])] = 1
+        if (N, K) in ((512, 256), (1024, 512)):
+            mask = pcf.degaBuild(N, K, 2.0)
+        code = _native.Code(_native.default_ctx(), mask)
+        B = 11
+        llr = (rs.standard_normal((B, N)) * 3 + 1).astype(dtype)
+        llr[0, :8] = 0.0  # exact zeros decide 0
+        monkeypatch.delenv("POLAR_SC_KERNEL", raising=False)
+        info, uh, dl = code.sc_decode(llr, want_uhat=True, want_llrs=True)
+        assert code.last_launch()["kernel"].startswith("sc_reg_full_kernel"), code.last_launch()
+        for b in range(B):
+            ruh, rdl = oracle.sc_decode(llr[b], mask, want_llrs=True)
+            assert np.array_equal(uh[b], ruh), (N, K, b)
+            assert np.array_equal(dl[b], rdl), (N, K, b)
+            assert np.array_equal(info[b], oracle.extract(ruh, mask))
+        monkeypatch.setenv("POLAR_SC_KERNEL", "lds")
+        info2, uh2, dl2 = code.sc_decode(llr, want_uhat=True, want_llrs=True)
+        assert np.array_equal(uh, uh2) and np.array_equal(dl, dl2) and np.array_equal(info, info2)
 
 
 @pytest.mark.parametrize("N", [2, 4, 8, 16, 32, 64])
@@ -199,9 +228,14 @@ def test_sc_every_compiled_16_leaf_profile(monkeypatch):
         ref_uh = np.stack([oracle.sc_decode(llr[b], mask) for b in range(llr.shape[0])])
         ref = ref_uh[:, mask == 1]
         for fast in (True, False):
+            monkeypatch.setenv("POLAR_SC_KERNEL", "lds")
             info, uh, _ = code.sc_decode(llr, want_uhat=True, fast=fast)      # LDS-staged kernel, no decision LLRs
+            monkeypatch.delenv("POLAR_SC_KERNEL")
             assert code.last_launch()["kernel"].startswith("sc_decode_kernel")
             assert np.array_equal(uh, ref_uh) and np.array_equal(info, ref), (dtype, fast)
+            info, uh, _ = code.sc_decode(llr, want_uhat=True, fast=False)     # the register kernel with side outputs
+            assert code.last_launch()["kernel"].startswith("sc_reg_full_kernel")
+            assert np.array_equal(uh, ref_uh) and np.array_equal(info, ref), dtype
             if dtype == np.float32:
                 info, _, _ = code.sc_decode(llr, fast=fast)
                 assert code.last_launch()["kernel"].startswith("sc_reg_kernel")
