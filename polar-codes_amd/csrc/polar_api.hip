@@ -126,47 +126,7 @@ extern "C" int polar_ctx_enable_timing(polar_ctx *c, int on)
 }
 
 // ---------------------------------------------------------------------------------------------- schedule
-// Depth-first walk of the code tree.  A node at `level` covers leaves [pos, pos + 2^level).
-static void walk(const uint8_t *mask, int level, int pos, int plane, bool fast, bool sub16, std::vector<uint32_t> &ops)
-{
-    int w = 1 << level;
-    int ninfo = 0;
-    for (int i = 0; i < w; i++) ninfo += mask[pos + i] ? 1 : 0;
-    if (fast && ninfo == 0) {
-        ops.push_back(make_op(OP_R0, level, plane));
-        return;
-    }
-    if (fast && ninfo == w && level > 0) {
-        ops.push_back(make_op(OP_R1, level, plane));
-        return;
-    }
-    if (level == 0) {
-        ops.push_back(make_op(mask[pos] ? OP_LEAF_INFO : OP_LEAF_FROZEN, 0, plane, pos));
-        return;
-    }
-    if (sub16 && level == 4) {
-        uint32_t m16 = 0;
-        for (int i = 0; i < 16; i++) m16 |= (uint32_t)(mask[pos + i] ? 1 : 0) << i;
-        ops.push_back(make_op(OP_SUB16, level, plane, m16));
-        return;
-    }
-    ops.push_back(make_op(OP_F, level, 0));
-    walk(mask, level - 1, pos, 0, fast, sub16, ops);
-    ops.push_back(make_op(OP_G, level, 0));
-    walk(mask, level - 1, pos + w / 2, 1, fast, sub16, ops);
-    ops.push_back(make_op(OP_COMBINE, level, plane));
-}
-
-std::vector<uint32_t> build_schedule(const uint8_t *mask, int N, bool fast, bool sub16)
-{
-    std::vector<uint32_t> ops;
-    int n = 0;
-    while ((1 << n) < N) n++;
-    walk(mask, n, 0, 0, fast, sub16 && n >= 5, ops);
-    ops.push_back(make_op(OP_END, 0, 0));
-    return ops;
-}
-
+// (the compiler itself is host-only code: host_tables.cpp)
 extern "C" int polar_schedule_build(const uint8_t *mask, int N, int fast, uint32_t *out, int cap)
 {
     ARG_TRY(mask != nullptr, "mask is NULL");
@@ -289,25 +249,8 @@ extern "C" int polar_code_set_crc(polar_code *c, uint64_t crc_poly)
         w = 63 - __builtin_clzll(crc_poly);
         ARG_TRY(w >= 1 && w <= 32, "CRC width (degree of crc_poly) must be in [1, 32]");
         ARG_TRY(w <= c->K, "CRC is wider than the code's information length");
-        const uint64_t keep = (1ull << w) - 1ull;
-        const uint64_t low = crc_poly & keep;
-        // R[p] = x^(p + w) mod g: what a one at distance p from the end of a word leaves in the remainder register
-        // of the MSB-first shift register after the word and w zeros went through (cn/functions.py:567-583)
-        std::vector<uint32_t> R(c->K);
-        uint64_t r = low;
-        for (int p = 0; p < c->K; p++) {
-            R[p] = (uint32_t)r;
-            const uint64_t top = (r >> (w - 1)) & 1ull;
-            r = ((r << 1) & keep) ^ (top ? low : 0ull);
-        }
-        const int Km = c->K - w;
-        std::vector<uint32_t> E(std::max(1, Km), 0), S(c->K);
-        for (int k = 0; k < Km; k++) {
-            uint32_t v = R[Km - 1 - k], t = 0;  // appended bit j is register bit w-1-j
-            for (int j = 0; j < w; j++) t |= ((v >> (w - 1 - j)) & 1u) << j;
-            E[k] = t;
-        }
-        for (int k = 0; k < c->K; k++) S[k] = R[c->K - 1 - k];
+        std::vector<uint32_t> E, S;
+        build_crc_tables(crc_poly, w, c->K, E, S);
         hipError_t e = hipMalloc((void **)&nE, E.size() * 4);
         if (e == hipSuccess) e = hipMalloc((void **)&nS, S.size() * 4);
         if (e == hipSuccess) e = hipMemcpy(nE, E.data(), E.size() * 4, hipMemcpyHostToDevice);
@@ -636,27 +579,6 @@ extern "C" int polar_scl_decode_genie_packed(polar_code *c, const void *llr, int
 }
 
 // ---------------------------------------------------------------------------------------------- bit flipping
-// First positions of the maximal subtrees whose leaves are all information bits with index > after.
-static void critical_heads(const std::vector<int> &pre, int lo, int size, int after, std::vector<int32_t> &out)
-{
-    const int ninfo = pre[lo + size] - pre[lo];
-    if (ninfo == 0) return;
-    if (ninfo == size) {
-        out.push_back(lo);
-        return;
-    }
-    critical_heads(pre, lo, size / 2, after, out);
-    critical_heads(pre, lo + size / 2, size / 2, after, out);
-}
-static std::vector<int32_t> critical_set(const uint8_t *mask, int N, int after)
-{
-    std::vector<int> pre(N + 1, 0);
-    for (int i = 0; i < N; i++) pre[i + 1] = pre[i] + ((mask[i] && i > after) ? 1 : 0);
-    std::vector<int32_t> out;
-    critical_heads(pre, 0, N, after, out);
-    return out;
-}
-
 extern "C" int polar_critical_set(const uint8_t *mask, int N, int after, int32_t *out, int cap)
 {
     ARG_TRY(mask != nullptr, "mask is NULL");

@@ -26,33 +26,7 @@ void polar_set_error(const char *fmt, ...);
         }                                                                                          \
     } while (0)
 
-// ---- decoder schedule -------------------------------------------------------------------------
-// One 32-bit word per operation; the list is the depth-first walk of the code tree.
-//   bits 0..3  type, bits 4..8 level (log2 of the width of the node the op belongs to),
-//   bit 9 destination plane of the node's partial sums (0 = node is a left child, 1 = right child),
-//   bits 12..31 leaf index (LEAF ops).
-enum : uint32_t {
-    OP_F = 0,        // level-(l-1) LLRs of the left child from the level-l LLRs (min-sum)
-    OP_G = 1,        // level-(l-1) LLRs of the right child, using the left child's partial sums
-    OP_LEAF_INFO = 2,
-    OP_LEAF_FROZEN = 3,
-    OP_R0 = 4,       // whole node frozen: partial sums are zero
-    OP_R1 = 5,       // whole node information: partial sums = hard decisions of its LLRs
-    OP_COMBINE = 6,  // node partial sums (xl ^ xr, xr) from its two children
-    OP_SUB16 = 7,    // a whole 16-leaf node decoded in registers; bits 12..27 = its rate profile (leaf i = bit i)
-    OP_END = 15
-};
-static inline uint32_t make_op(uint32_t type, uint32_t level, uint32_t plane, uint32_t leaf = 0)
-{
-    return type | (level << 4) | (plane << 9) | (leaf << 12);
-}
-#define OP_TYPE(w) ((w)&15u)
-#define OP_LEVEL(w) (((w) >> 4) & 31u)
-#define OP_PLANE(w) (((w) >> 9) & 1u)
-#define OP_LEAFIDX(w) ((w) >> 12)
-
-// sub16: 16-leaf nodes become one OP_SUB16 each instead of their 61 leaf-level operations
-std::vector<uint32_t> build_schedule(const uint8_t *mask, int N, bool fast, bool sub16 = false);
+#include "host_tables.h"  // decoder schedule encoding and the host-only table builders
 
 // ---- grow-only device buffer ------------------------------------------------------------------
 struct DevBuf {

@@ -1,0 +1,42 @@
+// Runs the host-only table builders of the library on many rate profiles; built with -fsanitize=address,undefined by
+// `make -C polar-codes_amd/csrc sanitize` and run by tests/test_sanitizers.py (CPU only).
+#include <stdio.h>
+
+#include "host_tables.h"
+
+int main()
+{
+    uint32_t st = 99u;
+    auto rnd = [&]() {
+        st = st * 1664525u + 1013904223u;
+        return st >> 8;
+    };
+    size_t total = 0;
+    for (int n = 1; n <= 12; n++) {
+        const int N = 1 << n;
+        for (int trial = 0; trial < 4; trial++) {
+            std::vector<uint8_t> mask(N);
+            int K = 0;
+            for (int i = 0; i < N; i++) {
+                mask[i] = trial == 0 ? 0 : trial == 1 ? 1 : trial == 2 ? (i >= N / 2) : (rnd() & 1);
+                K += mask[i];
+            }
+            for (int fast = 0; fast < 2; fast++)
+                for (int sub16 = 0; sub16 < 2; sub16++) {
+                    const std::vector<uint32_t> ops = build_schedule(mask.data(), N, fast != 0, sub16 != 0);
+                    if (ops.empty() || OP_TYPE(ops.back()) != OP_END) return 1;
+                    total += ops.size();
+                }
+            for (int after : {-1, 0, N / 2, N - 1}) total += critical_set(mask.data(), N, after).size();
+            for (int w : {1, 8, 24, 32}) {
+                if (w > K) continue;
+                std::vector<uint32_t> E, S;
+                build_crc_tables((1ull << w) | 0x7ull | (w > 4 ? 0x10ull : 0ull), w, K, E, S);
+                if ((int)S.size() != K) return 1;
+                total += E.size();
+            }
+        }
+    }
+    printf("host tables sanitizer run ok (%zu)\n", total);
+    return 0;
+}

@@ -60,6 +60,36 @@ def _all_reduce_counters(dist, counters, device):
     return np.array(t.cpu().tolist(), dtype=np.uint64)
 
 
+def _mask_id(pcode):
+    import hashlib
+
+    return hashlib.sha1(np.ascontiguousarray(np.asarray(pcode.polarMask) != 0, dtype=np.uint8).tobytes()).hexdigest()[:16]
+
+
+def _checkpoint_load(path, ident):
+    """State of an earlier, interrupted sweep with the same arguments, or an empty one."""
+    import json
+
+    if path and os.path.exists(path):
+        with open(path) as fh:
+            state = json.load(fh)
+        if state.get("ident") != ident:
+            raise ValueError("checkpoint %s was written for another sweep: %r" % (path, state.get("ident")))
+        return state
+    return {"ident": ident, "points": {}}
+
+
+def _checkpoint_save(path, state, rank):
+    import json
+
+    if not path or rank != 0:
+        return
+    tmp = path + ".tmp"
+    with open(tmp, "w") as fh:
+        json.dump(state, fh)
+    os.replace(tmp, path)  # never a half-written file
+
+
 def shard_range(total, rank, world):
     """Contiguous share [lo, hi) of `total` frames for `rank` (sizes differ by at most one)."""
     base, rem = divmod(int(total), int(world))
@@ -100,7 +130,7 @@ def native_runner(pcode, decoder, L, dtype, crc=False, genie=False):
 
 def simulate(pcode, snrRange, frames=None, errCnt=100, minFrames=100000, maxFrames=10 ** 8, seed=2024, decoder=None,
              L=None, dtype=np.float32, batch=1 << 18, snrType=None, modu=None, verbose=True, dist=None, runner=None,
-             reduce_device=None, isCRC=None, genie=False):
+             reduce_device=None, isCRC=None, genie=False, checkpoint=None):
     """Eb/N0 (or Es/N0) sweep.
 
     frames=int   -> exactly that many frames per SNR point (split evenly over the ranks);
@@ -113,6 +143,12 @@ def simulate(pcode, snrRange, frames=None, errCnt=100, minFrames=100000, maxFram
     infoLen - crcWidth bits, and rate and BER refer to the message (cn/simulator.py:20,133,360).
     genie=True (or decoder='scl-oracle') decodes with sclDecoderOracle, the call the reference's loop actually
     makes (cn/simulator.py:156): the transmitted word is returned whenever the final list holds it.
+    checkpoint=path keeps the state of the sweep in a small JSON file (the reference keeps results in memory only,
+    cn/simulator.py:109-115, 282-284): per SNR point its seed, the counters so far, the next round of the stopping-rule
+    mode and whether the point is finished; rank 0 rewrites it after every finished point and, in stopping-rule mode,
+    after every round.  A later call with the same arguments and the same file skips what is finished and continues
+    the point that was in progress with the frames it has not seen yet (frames are keyed by their global index, so the
+    totals equal those of an uninterrupted run).  A file written for other arguments is refused.
     Returns a BERFER; every rank returns the same totals.
     """
     rank, world, dist = _dist_state(dist)
@@ -140,22 +176,30 @@ def simulate(pcode, snrRange, frames=None, errCnt=100, minFrames=100000, maxFram
         if dist is not None and dist.get_backend() == "nccl":
             reduce_device = "cuda:%d" % int(os.environ.get("POLAR_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     result = BERFER()
+    ident = {"N": int(pcode.codewordLength), "K": int(pcode.infoLen), "mask_sha1": _mask_id(pcode), "decoder": decoder, "L": L,
+             "dtype": np.dtype(dtype).name, "snrType": snrType, "modu": modu, "isCRC": isCRC, "genie": bool(genie), "seed": int(seed),
+             "snrRange": [float(v) for v in snrRange], "frames": None if frames is None else int(frames), "errCnt": int(errCnt),
+             "minFrames": int(minFrames), "maxFrames": int(maxFrames), "batch": int(batch), "world": int(world)}
+    state = _checkpoint_load(checkpoint, ident)
     for ip, snr in enumerate(snrRange):
         snr = float(snr)
         if verbose and rank == 0:
             print(f"\nSNR = {snr} dB")
         ch = Channel(modu, snr, snrType, rate)
         pseed = int(seed) + ip
-        total = np.zeros(3, dtype=np.uint64)
-        t0 = time.perf_counter()
-        if frames is not None:
+        point = state["points"].get(str(ip), {"seed": pseed, "counters": [0, 0, 0], "next_round": 0, "done": False, "seconds": 0.0})
+        total = np.array(point["counters"], dtype=np.uint64)
+        t0 = time.perf_counter() - float(point["seconds"])
+        if point["done"]:
+            pass
+        elif frames is not None:
             lo, hi = shard_range(frames, rank, world)
             mine = np.zeros(3, dtype=np.uint64)
             for f0 in range(lo, hi, batch):
                 mine += run(ch.noisePower, pseed, f0, min(batch, hi - f0))
             total = _all_reduce_counters(dist, mine, reduce_device)
         else:
-            rnd = 0
+            rnd = int(point["next_round"])
             while True:
                 f0 = (rnd * world + rank) * batch
                 mine = run(ch.noisePower, pseed, f0, batch)
@@ -166,7 +210,12 @@ def simulate(pcode, snrRange, frames=None, errCnt=100, minFrames=100000, maxFram
                     print(f"\nt = {t} FER = {int(total[1]) / (t + 1):0.2e}")
                 if (int(total[1]) >= errCnt and t >= minFrames - 1) or int(total[0]) >= maxFrames:
                     break
+                state["points"][str(ip)] = {"seed": pseed, "counters": [int(v) for v in total], "next_round": rnd, "done": False,
+                                            "seconds": time.perf_counter() - t0}
+                _checkpoint_save(checkpoint, state, rank)
         dt = time.perf_counter() - t0
+        state["points"][str(ip)] = {"seed": pseed, "counters": [int(v) for v in total], "next_round": 0, "done": True, "seconds": dt}
+        _checkpoint_save(checkpoint, state, rank)
         nfr, fe, be = int(total[0]), int(total[1]), int(total[2])
         if verbose and rank == 0:
             print(f"\nAt {snr} dB FER is {fe / max(nfr, 1):0.2e}")
@@ -203,14 +252,16 @@ def main(argv=None):
     ap.add_argument("--crc", type=lambda s: int(s, 0), default=0,
                     help="CRC generator with its leading term, e.g. 0x107; K then counts message bits and the code "
                          "carries K + width information bits (cn/simulator.py:22)")
+    ap.add_argument("--checkpoint", default=None, help="JSON file that keeps the state of the sweep; a rerun continues from it")
     a = ap.parse_args(argv)
     dist = None
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl")
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     width = max(a.crc.bit_length() - 1, 0)
     pc = PolarCode(a.N, a.K + width, a.construct, a.dsnr, listSize=a.L)
     pc.decoderType, pc.snrType, pc.modu = a.decoder, "SNRb", "BPSK"
@@ -218,7 +269,7 @@ def main(argv=None):
     if a.decoder == "pbf":
         pc.maxLevel = a.L
     res = simulate(pc, a.snr, frames=a.frames, errCnt=a.errCnt, minFrames=a.minFrames, seed=a.seed,
-                   dtype=np.float64 if a.f64 else np.float32, dist=dist)
+                   dtype=np.float64 if a.f64 else np.float32, dist=dist, checkpoint=a.checkpoint)
     if dist is None or dist.get_rank() == 0:
         print(json.dumps(res.as_dict()))
     if dist is not None:

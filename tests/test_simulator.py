@@ -215,3 +215,33 @@ def test_bench_two_rank_rehearsal():
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["counters"][0] == 400000 and line["value"] > 0
+
+
+def test_checkpoint_resume_gives_the_uninterrupted_totals(tmp_path):
+    """simulate(checkpoint=...): a sweep that dies in the middle of a point (here: the frame runner raises) continues from
+    the file with the rounds it has not run, and ends with the totals of an uninterrupted sweep; finished points are not
+    run again; a file of another sweep is refused."""
+    pc = FakeCode(64, 32)
+    ck = str(tmp_path / "sweep.json")
+    kw = dict(frames=None, errCnt=60, minFrames=900, batch=100, seed=4, verbose=False)
+    whole = simulator.simulate(pc, [0.0, 1.0], runner=oracle_runner(pc), **kw)
+
+    calls = []
+
+    def dying(N0, seed, frame0, nframes):
+        calls.append((seed, frame0))
+        if len(calls) == 14:
+            raise RuntimeError("power cut")
+        return oracle.mc_run(pc.polarMask, 0, 1, 0, N0, seed, frame0, nframes)
+
+    with pytest.raises(RuntimeError):
+        simulator.simulate(pc, [0.0, 1.0], runner=dying, checkpoint=ck, **kw)
+    log = []
+    again = simulator.simulate(pc, [0.0, 1.0], runner=oracle_runner(pc, log), checkpoint=ck, **kw)
+    assert again.frames == whole.frames and again.frameErrors == whole.frameErrors and again.bitErrors == whole.bitErrors
+    assert len(log) + 13 == sum(f // 100 for f in whole.frames), "only the rounds that were missing have run"
+    log.clear()
+    third = simulator.simulate(pc, [0.0, 1.0], runner=oracle_runner(pc, log), checkpoint=ck, **kw)
+    assert not log and third.frameErrors == whole.frameErrors
+    with pytest.raises(ValueError):
+        simulator.simulate(pc, [0.0, 1.0], runner=oracle_runner(pc), checkpoint=ck, **dict(kw, seed=5))
