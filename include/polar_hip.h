@@ -211,6 +211,20 @@ int polar_sc_decode_count(polar_code *code, const void *llr, int dtype, const ui
 int polar_mc_run(polar_code *code, int decoder, int L, int dtype, int flags, double N0, uint64_t seed,
                  uint64_t frame0, int64_t nframes, uint64_t counters[3]);
 
+/* ---- counter reduction over the GPUs of one node: the reduction of frameError / bit errors over the workers of the
+ *      reference's parallel loop (mysimulator.m:85-118, parfor), for callers that drive every GPU from one process
+ *      (one polar_ctx per GPU).  polar_comm_init_all makes one RCCL communicator per listed device (ncclCommInitAll;
+ *      devices = NULL means 0 .. ndev-1); polar_allreduce_counters sums, in place, n uint64 counters over the devices:
+ *      dev_counters[i] is a device pointer on devices[i] (e.g. the uint64[3] that polar_count_errors adds to).  The call
+ *      returns when every device holds the totals; decoder work that writes the counters must have finished
+ *      (polar_ctx_sync).  RCCL is loaded on first use; without it POLAR_EUNSUPPORTED.  The Python driver
+ *      (simulator.simulate) runs one process per GPU and reduces through torch.distributed instead. */
+typedef struct polar_comm polar_comm;
+int polar_comm_init_all(int ndev, const int *devices, polar_comm **out);
+int polar_comm_destroy(polar_comm *comm);
+int polar_comm_size(const polar_comm *comm);
+int polar_allreduce_counters(polar_comm *comm, uint64_t *const *dev_counters, int n);
+
 /* ---- introspection for benchmarks: name, LDS bytes per frame and lanes per frame of the kernel the
  *      last SC/SCL decode call on this code launched, its grid size, and (when timing is enabled with
  *      polar_ctx_enable_timing) the duration of that launch in milliseconds from HIP events recorded

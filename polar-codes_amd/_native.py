@@ -71,6 +71,10 @@ SIGNATURES = {
     "polar_sc_decode_count": (_i, [_vp, _vp, _i, _vp, _vp, _i64, _i, _vp]),
     "polar_count_errors": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "polar_mc_run": (_i, [_vp, _i, _i, _i, _i, _d, _u64, _u64, _i64, _vp]),
+    "polar_comm_init_all": (_i, [_i, _vp, C.POINTER(_vp)]),
+    "polar_comm_destroy": (_i, [_vp]),
+    "polar_comm_size": (_i, [_vp]),
+    "polar_allreduce_counters": (_i, [_vp, _vp, _i]),
     "polar_last_launch": (_i, [_vp, C.POINTER(LaunchInfo)]),
 }
 
@@ -331,6 +335,32 @@ class Code:
 
     def count_errors_dev(self, info_ptr, hat_ptr, B, counters_ptr, crc=False):
         _check(lib().polar_count_errors(self._h, info_ptr, hat_ptr, B, CRC if crc else 0, counters_ptr))
+
+
+class Comm:
+    """RCCL communicators over GPUs driven from this one process (polar_comm_init_all)."""
+
+    def __init__(self, devices):
+        devs = (C.c_int * len(devices))(*devices)
+        self._h = C.c_void_p()
+        _check(lib().polar_comm_init_all(len(devices), devs, C.byref(self._h)))
+        self.devices = list(devices)
+
+    def allreduce_counters(self, dev_ptrs, n=3):
+        """Sum n uint64 counters over the devices, in place; dev_ptrs[i] = device pointer on devices[i]."""
+        arr = (C.c_void_p * len(dev_ptrs))(*[int(p) for p in dev_ptrs])
+        _check(lib().polar_allreduce_counters(self._h, arr, int(n)))
+
+    def close(self):
+        if self._h:
+            lib().polar_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def schedule_build(mask, fast, sub16=False):

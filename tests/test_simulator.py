@@ -245,3 +245,29 @@ def test_checkpoint_resume_gives_the_uninterrupted_totals(tmp_path):
     assert not log and third.frameErrors == whole.frameErrors
     with pytest.raises(ValueError):
         simulator.simulate(pc, [0.0, 1.0], runner=oracle_runner(pc), checkpoint=ck, **dict(kw, seed=5))
+
+
+@pytest.mark.gpu
+def test_c_abi_counter_allreduce_over_rccl():
+    """polar_comm_init_all / polar_allreduce_counters: RCCL communicators made inside one process over the visible GPUs
+    (one on the test box), counters of polar_count_errors summed in place."""
+    import torch
+
+    import _native
+
+    ndev = torch.cuda.device_count()
+    comm = _native.Comm(list(range(ndev)))
+    bufs = []
+    for d in range(ndev):
+        with torch.cuda.device(d):
+            bufs.append(torch.tensor([100 + d, 7 * (d + 1), 3], dtype=torch.int64, device="cuda:%d" % d))
+    torch.cuda.synchronize()
+    comm.allreduce_counters([b.data_ptr() for b in bufs], 3)
+    want = [sum(100 + d for d in range(ndev)), sum(7 * (d + 1) for d in range(ndev)), 3 * ndev]
+    for b in bufs:
+        assert b.cpu().tolist() == want
+    comm.close()
+    with pytest.raises(_native.PolarError):
+        _native.Comm(list(range(ndev + 1)))
+    with pytest.raises(_native.PolarError):
+        _native.Comm([0, 0][: max(2, ndev)]) if ndev >= 2 else _native.Comm([5])
