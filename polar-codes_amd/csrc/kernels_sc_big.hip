@@ -48,7 +48,7 @@ template <int NLOG> struct BigLayout {
 };
 
 template <int NLOG> struct BigCtx {
-    RegDec<float, 10, 0, true> d;
+    RegDec<float, 10, 0, false, true> d;  // the subtree's 1024 LLRs arrive in registers (d.Ch)
     RowConst rc;
     BigTables t;
     float *slab;          // this frame's slab
@@ -56,36 +56,90 @@ template <int NLOG> struct BigCtx {
     int sub;
 };
 
+// the lane's index / the frame's slab pointer through an opaque copy (see big_step)
+__device__ __forceinline__ int opaque_idx(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ float *opaque_ptr(float *p)
+{
+    asm volatile("" : "+v"(p));
+    return p;
+}
+
 // f / g from level LEV to LEV-1 (LEV >= 11): elements sub + 16 j of the lane's residue, four (j = 4 J .. 4 J + 3) per trip.
-// The channel itself is in natural order (4-byte accesses); every level of the slab is in the order described above.
-template <int LEV, int NLOG, bool IS_G> __device__ __forceinline__ void big_step(BigCtx<NLOG> &cx)
+// The channel itself is in natural order (4-byte accesses); every level of the slab is in the order described above;
+// level 10, the LLRs of one 1024-leaf subtree, is never stored: it goes to the registers cx.d.Ch (element 16 j + sub at Ch[j]).
+// FUSE: the step that follows at once, the f from level LEV-1 to LEV-2 of the left child, is done on the way (its
+// operands are trips J and J + trips/2 of this step's results), which saves reading level LEV-1 back.
+template <int LEV, int NLOG, bool IS_G> __device__ __forceinline__ float4 big_trip(BigCtx<NLOG> &cx, const float *slab, const uint32_t *bits, int J, int sq)
 {
     typedef BigLayout<NLOG> Lay;
     constexpr int half = 1 << (LEV - 1);
-    float *out = cx.slab + Lay::llr_off(LEV - 1) + 4 * cx.sub;
-    const uint32_t *bits = reinterpret_cast<const uint32_t *>(cx.slab) + Lay::ps_off(LEV - 1, 0) + cx.sub;
+    float4 a, b;
+    if constexpr (LEV == NLOG) {
+        const float *in = cx.chan + 64 * J + sq;
+        a = make_float4(in[0], in[16], in[32], in[48]);
+        b = make_float4(in[half], in[half + 16], in[half + 32], in[half + 48]);
+    } else {
+        const float *in = slab + Lay::llr_off(LEV) + 64 * J + 4 * sq;
+        a = *reinterpret_cast<const float4 *>(in);
+        b = *reinterpret_cast<const float4 *>(in + half);
+    }
+    if (IS_G) {
+        const uint32_t w = bits[(J >> 3) * 16] >> ((4 * J) & 31);
+        return make_float4(g_fast(a.x, b.x, w & 1u), g_fast(a.y, b.y, (w >> 1) & 1u), g_fast(a.z, b.z, (w >> 2) & 1u),
+                           g_fast(a.w, b.w, (w >> 3) & 1u));
+    }
+    return make_float4(f_fast(a.x, b.x), f_fast(a.y, b.y), f_fast(a.z, b.z), f_fast(a.w, b.w));
+}
+template <int L, int NLOG> __device__ __forceinline__ void big_put(BigCtx<NLOG> &cx, float *slab, int J, const float4 &r, int sq)
+{
+    typedef BigLayout<NLOG> Lay;
+    if constexpr (L == 10) {  // J is a compile-time constant here: the loops over level-10 trips are fully unrolled
+        cx.d.Ch[4 * J] = r.x;
+        cx.d.Ch[4 * J + 1] = r.y;
+        cx.d.Ch[4 * J + 2] = r.z;
+        cx.d.Ch[4 * J + 3] = r.w;
+    } else {
+        *reinterpret_cast<float4 *>(slab + Lay::llr_off(L) + 4 * sq + 64 * J) = r;
+    }
+}
+template <int LEV, int NLOG, bool IS_G, bool FUSE> __device__ __forceinline__ void big_step(BigCtx<NLOG> &cx)
+{
+    typedef BigLayout<NLOG> Lay;
+    constexpr int half = 1 << (LEV - 1);
+    // the lane's index goes through an opaque copy: addresses derived from it are formed here, base plus instruction
+    // offset, instead of being hoisted out of the frame loop as one register pair per access
+    int sq = cx.sub;
+    asm volatile("" : "+v"(sq));
+    float *slab = opaque_ptr(cx.slab);
+    const uint32_t *bits = reinterpret_cast<const uint32_t *>(slab) + Lay::ps_off(LEV - 1, 0) + sq;
     constexpr int trips = half / 64;  // four elements per lane and trip
+    if constexpr (!FUSE) {
+        if constexpr (LEV - 1 == 10) {
+#pragma unroll
+            for (int J = 0; J < trips; J++) big_put<LEV - 1, NLOG>(cx, slab, J, big_trip<LEV, NLOG, IS_G>(cx, slab, bits, J, sq), sq);
+        } else {
 #pragma unroll 4
-    for (int J = 0; J < trips; J++) {
-        float4 a, b;
-        if constexpr (LEV == NLOG) {
-            const float *in = cx.chan + 64 * J + cx.sub;
-            a = make_float4(in[0], in[16], in[32], in[48]);
-            b = make_float4(in[half], in[half + 16], in[half + 32], in[half + 48]);
-        } else {
-            const float *in = cx.slab + Lay::llr_off(LEV) + 64 * J + 4 * cx.sub;
-            a = *reinterpret_cast<const float4 *>(in);
-            b = *reinterpret_cast<const float4 *>(in + half);
+            for (int J = 0; J < trips; J++) big_put<LEV - 1, NLOG>(cx, slab, J, big_trip<LEV, NLOG, IS_G>(cx, slab, bits, J, sq), sq);
         }
-        float4 r;
-        if (IS_G) {
-            const uint32_t w = bits[(J >> 3) * 16] >> ((4 * J) & 31);
-            r = make_float4(g_fast(a.x, b.x, w & 1u), g_fast(a.y, b.y, (w >> 1) & 1u), g_fast(a.z, b.z, (w >> 2) & 1u),
-                            g_fast(a.w, b.w, (w >> 3) & 1u));
+    } else {
+        static_assert(!FUSE || LEV >= 12, "the fused f writes level LEV-2 >= 10");
+        auto body = [&](int J) {
+            const float4 r1 = big_trip<LEV, NLOG, IS_G>(cx, slab, bits, J, sq), r2 = big_trip<LEV, NLOG, IS_G>(cx, slab, bits, J + trips / 2, sq);
+            big_put<LEV - 1, NLOG>(cx, slab, J, r1, sq);
+            big_put<LEV - 1, NLOG>(cx, slab, J + trips / 2, r2, sq);
+            big_put<LEV - 2, NLOG>(cx, slab, J, make_float4(f_fast(r1.x, r2.x), f_fast(r1.y, r2.y), f_fast(r1.z, r2.z), f_fast(r1.w, r2.w)), sq);
+        };
+        if constexpr (LEV - 2 == 10) {
+#pragma unroll
+            for (int J = 0; J < trips / 2; J++) body(J);
         } else {
-            r = make_float4(f_fast(a.x, b.x), f_fast(a.y, b.y), f_fast(a.z, b.z), f_fast(a.w, b.w));
+#pragma unroll 2
+            for (int J = 0; J < trips / 2; J++) body(J);
         }
-        *reinterpret_cast<float4 *>(out + 64 * J) = r;
     }
 }
 
@@ -93,38 +147,51 @@ template <int LEV, int NLOG, bool IS_G> __device__ __forceinline__ void big_step
 template <int L, int NLOG> __device__ __forceinline__ void big_rate0(BigCtx<NLOG> &cx, int plane)
 {
     typedef BigLayout<NLOG> Lay;
-    uint32_t *ps = reinterpret_cast<uint32_t *>(cx.slab) + Lay::ps_off(L, plane);
-    for (int w = 0; w < (1 << (L - 9)); w++) ps[w * 16 + cx.sub] = 0u;
+    uint32_t *ps = reinterpret_cast<uint32_t *>(opaque_ptr(cx.slab)) + Lay::ps_off(L, plane) + opaque_idx(cx.sub);
+    for (int w = 0; w < (1 << (L - 9)); w++) ps[w * 16] = 0u;
 }
 template <int L, int NLOG> __device__ __forceinline__ void big_rate1(BigCtx<NLOG> &cx, int plane)
 {
     typedef BigLayout<NLOG> Lay;
-    uint32_t *ps = reinterpret_cast<uint32_t *>(cx.slab) + Lay::ps_off(L, plane);
-    const float *v = cx.slab + Lay::llr_off(L);
+    const int sq = opaque_idx(cx.sub);
+    float *slab = opaque_ptr(cx.slab);
+    uint32_t *ps = reinterpret_cast<uint32_t *>(slab) + Lay::ps_off(L, plane);
+    if constexpr (L == 10) {  // the subtree's LLRs are in registers
+#pragma unroll
+        for (int w = 0; w < 2; w++) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int i = 0; i < 32; i++) x |= (cx.d.Ch[32 * w + i] < 0.0f ? 1u : 0u) << i;
+            ps[w * 16 + sq] = x;
+        }
+        return;
+    }
+    const float *v = slab + Lay::llr_off(L);
     for (int w = 0; w < (1 << (L - 9)); w++) {
         uint32_t x = 0;
 #pragma unroll 8
-        for (int i = 0; i < 32; i++) x |= (v[64 * ((32 * w + i) >> 2) + 4 * cx.sub + (i & 3)] < 0.0f ? 1u : 0u) << i;
-        ps[w * 16 + cx.sub] = x;
+        for (int i = 0; i < 32; i++) x |= (v[64 * ((32 * w + i) >> 2) + 4 * sq + (i & 3)] < 0.0f ? 1u : 0u) << i;
+        ps[w * 16 + sq] = x;
     }
 }
 // parent (level LEV, plane) = [xl ^ xr, xr] of its children (level LEV-1, planes 0 and 1): whole words per lane
 template <int LEV, int NLOG> __device__ __forceinline__ void big_combine(BigCtx<NLOG> &cx, int plane)
 {
     typedef BigLayout<NLOG> Lay;
-    uint32_t *base = reinterpret_cast<uint32_t *>(cx.slab);
+    uint32_t *base = reinterpret_cast<uint32_t *>(opaque_ptr(cx.slab)) + opaque_idx(cx.sub);
     const uint32_t *xl = base + Lay::ps_off(LEV - 1, 0), *xr = base + Lay::ps_off(LEV - 1, 1);
     uint32_t *x = base + Lay::ps_off(LEV, plane);
     constexpr int nw = 1 << (LEV - 10);  // words per lane of a child
     for (int w = 0; w < nw; w++) {
-        const uint32_t l = xl[w * 16 + cx.sub], r = xr[w * 16 + cx.sub];
-        x[w * 16 + cx.sub] = l ^ r;
-        x[(nw + w) * 16 + cx.sub] = r;
+        const uint32_t l = xl[w * 16], r = xr[w * 16];
+        x[w * 16] = l ^ r;
+        x[(nw + w) * 16] = r;
     }
 }
 
-// node idx of level LEV >= 11, not all-frozen and not all-information; a two-trip loop over the children as in decode_node
-template <int LEV, int NLOG> __device__ void big_node(BigCtx<NLOG> &cx, uint32_t idx, int plane)
+// node idx of level LEV >= 11, not all-frozen and not all-information; a two-trip loop over the children as in decode_node.
+// have_f: the caller's step has already produced the LLRs of this node's left child (fused f).
+template <int LEV, int NLOG> __device__ __forceinline__ void big_node(BigCtx<NLOG> &cx, uint32_t idx, int plane, bool have_f)
 {
     typedef BigLayout<NLOG> Lay;
 #pragma nounroll
@@ -136,31 +203,53 @@ template <int LEV, int NLOG> __device__ void big_node(BigCtx<NLOG> &cx, uint32_t
             big_rate0<LEV - 1, NLOG>(cx, (int)h);  // an all-frozen child needs no LLRs
             continue;
         }
-        if (h == 0) big_step<LEV, NLOG, false>(cx);
-        else big_step<LEV, NLOG, true>(cx);
+        // the child's own first step, the f for its left child, rides along when the child is a mixed node above the
+        // subtrees and that left child is not all-frozen
+        bool fuse = false;
+        if constexpr (LEV >= 12) fuse = !is1 && !((cx.t.up_r0[LEV - 2 - 10] >> (2 * cidx)) & 1ull);
+        if (h == 0) {
+            if (!have_f) {
+                if constexpr (LEV >= 12) {
+                    if (fuse) big_step<LEV, NLOG, false, true>(cx);
+                    else big_step<LEV, NLOG, false, false>(cx);
+                } else {
+                    big_step<LEV, NLOG, false, false>(cx);
+                }
+            } else if constexpr (LEV >= 12) {
+                // level LEV-1 is there already; the grandchild's f still has to be done by the child itself
+                fuse = false;
+            }
+        } else {
+            if constexpr (LEV >= 12) {
+                if (fuse) big_step<LEV, NLOG, true, true>(cx);
+                else big_step<LEV, NLOG, true, false>(cx);
+            } else {
+                big_step<LEV, NLOG, true, false>(cx);
+            }
+        }
         if (is1) {
             big_rate1<LEV - 1, NLOG>(cx, (int)h);
         } else if constexpr (LEV - 1 == 10) {
-            // one 1024-leaf subtree in registers: its channel is the slab's level 10
+            // one 1024-leaf subtree in registers: its LLRs are in cx.d.Ch
             const int lane = (int)threadIdx.x;
             const uint32_t maskv = cx.t.maskw[32 * cidx + (lane & 31)];
             const uint32_t pidv = cx.t.pid16[64 * cidx + lane];
             const NodeClasses nc = cx.t.sub[cidx];
             cx.d.ps0 = cx.d.ps1 = 0;
             cx.d.root = 0;
-            decode_node<10, 10, true>(cx.d, nc, maskv, pidv, cx.slab + Lay::llr_off(10) + 4 * cx.sub, 0u, 0, cx.rc);
-            uint32_t *ps = reinterpret_cast<uint32_t *>(cx.slab) + Lay::ps_off(10, (int)h);
-            ps[cx.sub] = (uint32_t)cx.d.root;
-            ps[16 + cx.sub] = (uint32_t)(cx.d.root >> 32);
+            decode_node<10, 10, true>(cx.d, nc, maskv, pidv, nullptr, 0u, 0, cx.rc);
+            uint32_t *ps = reinterpret_cast<uint32_t *>(opaque_ptr(cx.slab)) + Lay::ps_off(10, (int)h) + opaque_idx(cx.sub);
+            ps[0] = (uint32_t)cx.d.root;
+            ps[16] = (uint32_t)(cx.d.root >> 32);
         } else {
-            big_node<LEV - 1, NLOG>(cx, cidx, (int)h);
+            big_node<LEV - 1, NLOG>(cx, cidx, (int)h, fuse);
         }
     }
     big_combine<LEV, NLOG>(cx, plane);
 }
 
 template <int NLOG>
-__global__ void __launch_bounds__(64, 4) sc_big_kernel(const float *__restrict__ llr, BigTables t, float *__restrict__ slabs,
+__global__ void __launch_bounds__(64, 3) sc_big_kernel(const float *__restrict__ llr, BigTables t, float *__restrict__ slabs,
                                                     uint32_t *__restrict__ info_hat, int64_t B, int K, int Kw)
 {
     typedef BigLayout<NLOG> Lay;
@@ -181,7 +270,7 @@ __global__ void __launch_bounds__(64, 4) sc_big_kernel(const float *__restrict__
         const bool active = f < B;
         const int64_t fc = active ? f : B - 1;
         cx.chan = llr + fc * N;
-        big_node<NLOG, NLOG>(cx, 0u, 0);
+        big_node<NLOG, NLOG>(cx, 0u, 0, false);
 
         // u_hat = x_hat F^{(x)n} on the sliced root (bit j of lane s = element 16 j + s; 2^(NLOG-9) words per lane)
         uint32_t *x = reinterpret_cast<uint32_t *>(cx.slab) + Lay::ps_off(NLOG, 0);

@@ -28,8 +28,11 @@ template <int BEGIN, int END, typename F> __device__ __forceinline__ void static
 
 // QUADS: the "channel" is an array the caller laid out for 16-byte accesses, element 16 j + lane at index
 // 64 (j / 4) + 4 lane + j % 4 (chan_lane then points at index 4 lane); otherwise element 16 j + lane at 16 j + lane.
-template <typename T, int NLOG, int KEEP = 0, bool QUADS = false> struct RegDec {
+// REGCH: the "channel" is not in memory at all but in the lane's registers Ch[0 .. 2^(NLOG-4)), element 16 j + lane at
+// Ch[j] (the long-code kernel hands its 1024-leaf subtrees over this way).
+template <typename T, int NLOG, int KEEP = 0, bool QUADS = false, bool REGCH = false> struct RegDec {
     typedef T value_type;
+    T Ch[REGCH ? (1 << (NLOG - 4)) : 1];
     static __device__ __forceinline__ constexpr int chan_index(int j) { return QUADS ? 64 * (j >> 2) + (j & 3) : 16 * j; }
     static constexpr int S = 1 << (NLOG - 4);  // slice length per lane
     T R[S];                                    // level l (4 <= l < NLOG): 2^(l-4) values at offset 2^(l-4)
@@ -43,6 +46,14 @@ template <typename T, int NLOG, int KEEP = 0, bool QUADS = false> struct RegDec 
     template <int LEV, bool IS_G> __device__ __forceinline__ void step(const T *chan_lane)
     {
         constexpr int c = 1 << (LEV - 5);
+        if constexpr (REGCH && LEV == NLOG) {
+#pragma unroll
+            for (int j = 0; j < c; j++) {
+                if constexpr (IS_G) R[c + j] = g_fast(Ch[j], Ch[j + c], (uint32_t)(ps0 >> (c + j)) & 1u);
+                else R[c + j] = f_fast(Ch[j], Ch[j + c]);
+            }
+            return;
+        }
         if constexpr (QUADS && LEV == NLOG && c >= 4 && sizeof(T) == 4) {
             // four elements of the lane per 16-byte load
 #pragma unroll
