@@ -90,7 +90,7 @@ extern "C" int polar_ctx_destroy(polar_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->in_bytes, &c->out_bytes, &c->in_words, &c->out_words, &c->llr_buf,   &c->aux_buf,  &c->aux2_buf,
                       &c->pm_buf,   &c->counters,  &c->mc_info,  &c->mc_hat,    &c->flip_rows, &c->flip_ctr, &c->flip_small,
-                      &c->mc_llr2,  &c->mc_info2,  &c->scl_slab};
+                      &c->mc_llr2,  &c->mc_info2,  &c->scl_slab,  &c->flip_pairs};
     for (DevBuf *b : bufs) b->release();
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
@@ -640,18 +640,25 @@ static int ensure_flip_tables(polar_code *c, bool need_lists)
 // Device-side body: fast SC on every frame, CRC test, search kernel on the frames that failed.
 // wi: packed information words out; d_runs / d_ok / d_last: device side outputs or NULL.
 // rows (one word per frame) and ctr (two 64-bit words: work counter, row count) are the scratch of the call.
+// split: workspace of the two-flip search in (frame, first flip) pieces, or NULL for one wavefront per frame.
 static int pbf_device_on(polar_code *c, const void *dl, int dtype, int max_level, uint32_t *wi, int32_t *d_runs, uint8_t *d_ok,
-                         int32_t *d_last, int64_t nb, uint32_t *rows, unsigned long long *ctr)
+                         int32_t *d_last, int64_t nb, uint32_t *rows, unsigned long long *ctr, const PbfSplit *split = nullptr)
 {
     polar_ctx *ctx = c->ctx;
     int rc;
     HIP_TRY(hipMemsetAsync(ctr, 0, 16, ctx->stream));
+    if (split) HIP_TRY(hipMemsetAsync(split->ctr, 0, 16, ctx->stream));
     if ((rc = launch_sc_decode(c, dl, dtype, wi, nullptr, nullptr, nb, POLAR_SC_FAST))) return rc;
     if ((rc = launch_crc_filter(c, wi, rows, ctr + 1, d_runs, d_ok, d_last, nb))) return rc;
     if (max_level >= 1)
-        rc = launch_pbf(c, dl, dtype, rows, ctr + 1, ctr, nullptr, max_level, true, wi, nullptr, nullptr, d_runs, d_ok, d_last, nb);
+        rc = launch_pbf(c, dl, dtype, rows, ctr + 1, ctr, nullptr, max_level, true, wi, nullptr, nullptr, d_runs, d_ok, d_last, nb,
+                        split);
     return rc;
 }
+
+// Frames per pass of the two-flip search: bounds its workspace (a frame that fails every single flip keeps
+// 12 + 2 nS0 bytes) whatever the batch size.
+static const int64_t PBF_SPLIT_FRAMES = (int64_t)1 << 18;
 
 static int pbf_device(polar_code *c, const void *dl, int dtype, int max_level, uint32_t *wi, int32_t *d_runs, uint8_t *d_ok,
                       int32_t *d_last, int64_t nb)
@@ -659,9 +666,30 @@ static int pbf_device(polar_code *c, const void *dl, int dtype, int max_level, u
     polar_ctx *ctx = c->ctx;
     int rc;
     if ((rc = ensure_flip_tables(c, max_level >= 2))) return rc;
-    if ((rc = ctx->flip_rows.reserve(nb * 4)) || (rc = ctx->flip_ctr.reserve(16))) return rc;
-    return pbf_device_on(c, dl, dtype, max_level, wi, d_runs, d_ok, d_last, nb, ctx->flip_rows.as<uint32_t>(),
-                         ctx->flip_ctr.as<unsigned long long>());
+    if ((rc = ctx->flip_rows.reserve(nb * 4)) || (rc = ctx->flip_ctr.reserve(32))) return rc;
+    uint32_t *rows = ctx->flip_rows.as<uint32_t>();
+    unsigned long long *ctr = ctx->flip_ctr.as<unsigned long long>();
+    const char *sw = getenv("POLAR_PBF_SPLIT");
+    const bool whole_frames = sw && atoi(sw) == 0;
+    if (max_level != 2 || whole_frames) return pbf_device_on(c, dl, dtype, max_level, wi, d_runs, d_ok, d_last, nb, rows, ctr);
+    // two flips: the second level is worked on in (frame, first flip) pieces, PBF_SPLIT_FRAMES frames at a time
+    const int64_t cap = std::min(nb, PBF_SPLIT_FRAMES);
+    const size_t rec = (size_t)std::max(c->nS0, 1) * 2;
+    const size_t off_best = ((size_t)cap * 4 + 255) & ~(size_t)255, off_rec = off_best + (size_t)cap * 8;
+    if ((rc = ctx->flip_pairs.reserve(off_rec + (size_t)cap * rec))) return rc;
+    PbfSplit sp;
+    sp.ctr = ctr + 2;
+    sp.rows2 = ctx->flip_pairs.as<uint32_t>();
+    sp.best = reinterpret_cast<unsigned long long *>(ctx->flip_pairs.as<char>() + off_best);
+    sp.order_rec = reinterpret_cast<uint16_t *>(ctx->flip_pairs.as<char>() + off_rec);
+    const size_t es = llr_size(dtype);
+    for (int64_t b0 = 0; b0 < nb; b0 += cap) {
+        const int64_t m = std::min(cap, nb - b0);
+        if ((rc = pbf_device_on(c, (const char *)dl + b0 * c->N * es, dtype, 2, wi + b0 * c->Kw, d_runs ? d_runs + b0 : nullptr,
+                                d_ok ? d_ok + b0 : nullptr, d_last ? d_last + 3 * b0 : nullptr, m, rows, ctr, &sp)))
+            return rc;
+    }
+    return POLAR_OK;
 }
 
 static int pbf_common(polar_code *c, const void *llr, int dtype, int max_level, void *info_hat, int32_t *runs, uint8_t *crc_ok,

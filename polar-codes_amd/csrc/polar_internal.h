@@ -51,6 +51,7 @@ struct polar_ctx {
     DevBuf in_bytes, out_bytes, in_words, out_words, llr_buf, aux_buf, aux2_buf, pm_buf, counters, mc_info, mc_hat, scl_slab;
     DevBuf mc_llr2, mc_info2;  // second buffers of the Monte-Carlo pipeline
     DevBuf flip_rows, flip_ctr, flip_small;  // failing-frame list, {work counter, row count}, per-frame side outputs
+    DevBuf flip_pairs;                       // two-flip search: frames, best pairs and ranked first flips of the frames it works on
 };
 
 struct polar_code {
@@ -119,9 +120,18 @@ int launch_scl_decode(polar_code *c, const void *llr, int dtype, int L, uint32_t
 // nbits: leading bits of each K-bit word that are compared
 int launch_count_errors(polar_code *c, const uint32_t *info, const uint32_t *hat, int64_t B, uint64_t *counters, int nbits);
 
+// Workspace of the two-flip search split into (frame, first flip) work items: ctr = {work counter, number of frames
+// that failed every single flip} (zero at launch), rows2 / best one entry per frame that may get there, order_rec
+// nS0 entries per such frame.
+struct PbfSplit {
+    unsigned long long *ctr;
+    uint32_t *rows2;
+    unsigned long long *best;
+    uint16_t *order_rec;
+};
 int launch_pbf(polar_code *c, const void *llr, int dtype, const uint32_t *rows, const unsigned long long *nrows_dev,
                unsigned long long *work, const int32_t *flips_in, int max_level, bool crc, uint32_t *info_hat, uint32_t *u_hat,
-               void *dec_llr, int32_t *runs, uint8_t *crc_ok, int32_t *last_seq, int64_t B);
+               void *dec_llr, int32_t *runs, uint8_t *crc_ok, int32_t *last_seq, int64_t B, const PbfSplit *split = nullptr);
 int launch_crc_filter(polar_code *c, const uint32_t *info_hat, uint32_t *rows, unsigned long long *nrows, int32_t *runs,
                       uint8_t *crc_ok, int32_t *last_seq, int64_t B);
 

@@ -169,6 +169,46 @@ def test_gpu_pbf_equals_oracle_on_random_frames(N, K, poly, T, nfr, dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,K,poly,nfr,snr,dtype", [(1024, 536, 0x1800063, 6000, 2.0, 0), (128, 72, 0x107, (1 << 18) + 777, 3.0, 0),
+                                                     (256, 140, 0x1621, 4000, 1.5, 1)])
+def test_gpu_pbf_two_flips_in_pieces_equals_whole_frame_search(N, K, poly, nfr, snr, dtype, monkeypatch):
+    """Two flips: the search worked on in (frame, first flip) pieces by many wavefronts gives the runs, flips, CRC
+    flags and bits of the search one wavefront makes per frame (which the oracle tests pin), also when the batch
+    takes more than one pass of the workspace."""
+    import torch
+
+    mask, mu = pcf.degaBuild(N, K, 2.0), pcf.GA(N, K, 2.0)
+    w = poly.bit_length() - 1
+    n0 = n0_ebn0(snr, (K - w) / N)
+    code = _native.Code(_native.default_ctx(), mask)
+    code.set_crc(poly)
+    code.set_reliability(mu)
+    npdt = np.float64 if dtype else np.float32
+    dev = torch.device("cuda:0")
+    info_t = torch.zeros((nfr, code.Kw), dtype=torch.int32, device=dev)
+    llr_t = torch.empty((nfr, N), dtype=torch.float64 if dtype else torch.float32, device=dev)
+    code.gen_frames_dev(info_t.data_ptr(), llr_t.data_ptr(), npdt, n0, 5, 0, nfr, crc=True)
+
+    def search():
+        hat = torch.zeros((nfr, code.Kw), dtype=torch.int32, device=dev)
+        runs = torch.zeros(nfr, dtype=torch.int32, device=dev)
+        ok = torch.zeros(nfr, dtype=torch.uint8, device=dev)
+        last = torch.zeros((nfr, 3), dtype=torch.int32, device=dev)
+        code.pbf_decode_dev(llr_t.data_ptr(), npdt, 2, hat.data_ptr(), nfr, runs_ptr=runs.data_ptr(), ok_ptr=ok.data_ptr(),
+                            last_ptr=last.data_ptr())
+        code.ctx.sync()
+        return hat.cpu().numpy(), runs.cpu().numpy(), ok.cpu().numpy(), last.cpu().numpy(), code.last_launch()["kernel"]
+
+    pieces = search()
+    monkeypatch.setenv("POLAR_PBF_SPLIT", "0")
+    whole = search()
+    assert pieces[4].endswith("+pairs") and not whole[4].endswith("+pairs")
+    for a, b in zip(pieces[:4], whole[:4]):
+        assert np.array_equal(a, b)
+    assert (whole[3][:, 1] >= 0).any() and (whole[2] == 0).any()   # some frames needed two flips, some found none
+
+
+@pytest.mark.gpu
 def test_gpu_pbf_argument_errors():
     code = _native.Code(_native.default_ctx(), pcf.degaBuild(64, 32, 2.0))
     llr = np.ones((2, 64), dtype=np.float32)
