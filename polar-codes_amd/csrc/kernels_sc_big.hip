@@ -1,16 +1,24 @@
 // SC decoder for codes longer than the register kernels hold (2048 <= N <= 65536, fp32, information bits).
 //
 // The same mapping as sc_reg_kernel -- sixteen lanes per frame, four frames per wavefront, element k of every
-// tree level in lane k mod 16 -- with the levels of width >= 1024 in a slab of global memory per frame (level l at
-// offset 2^l - 1024, N - 1024 floats in all; it stays in the L2 / Infinity Cache) and their partial sums beside it
-// as per-lane bit slices.  A lane only ever touches the elements of its own residue, so the slab needs no
-// synchronisation at all, and the order of a level inside the slab is free: element 16 j + s sits at index
-// 64 (j / 4) + 4 s + j % 4, four elements of a lane side by side, so that the steps above the subtrees move 16 bytes
-// per lane and 256 contiguous bytes per frame and instruction (4-byte accesses, 64 bytes per frame, reach only two
-// thirds of the memory rate).  Every 1024-leaf subtree is handed to the register-resident walk of sc_reg_kernel
-// (kernels_sc_node.h) with the slab's level 10 as its channel; all-frozen and all-information nodes of 1024 leaves
-// and more are short-cut as in the other kernels.  The output stage transforms the sliced root (x_hat -> u_hat),
-// writes it to the slab and gathers the information bits through a table.
+// tree level in lane k mod 16.  Where a level lives depends on its width:
+//   * levels of 4096 elements and more (below the channel) in a slab of global memory per frame (level l at offset
+//     2^l - 1024) with their partial sums beside them as per-lane bit slices.  A lane only ever touches the elements
+//     of its own residue, so the slab needs no synchronisation at all, and the order of a level inside the slab is
+//     free: element 16 j + s sits at index 64 (j / 4) + 4 s + j % 4, four elements of a lane side by side, so that a
+//     step moves 16 bytes per lane and 256 contiguous bytes per frame and instruction;
+//   * level 11 (2048 elements) on chip: its first half in 64 registers per lane, its second half in LDS (16 KB per
+//     wavefront);
+//   * level 10, the LLRs of one 1024-leaf subtree, nowhere: the two top-level steps of the subtree walk recompute
+//     them from level 11 (one f or g each) when they need them;
+//   * everything below in the registers of the subtree walk of sc_reg_kernel (kernels_sc_node.h).
+// A step above the subtrees (f or g from level l to l-1) also does the f steps that would follow it down the left
+// spine while its results are still in registers (up to three levels at once), so a level of the slab is written
+// once and read once, by the g step of its node.  HBM traffic per frame at N = 16384: the channel twice, levels 13
+// and 12 written and read once each, 428 KB measured (1041 KB with every level stored and every step on its own).
+// All-frozen and all-information nodes of 1024 leaves and more are short-cut as in the other kernels.  The output
+// stage transforms the sliced root (x_hat -> u_hat), writes it to the slab and gathers the information bits
+// through a table.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -47,8 +55,67 @@ template <int NLOG> struct BigLayout {
     static constexpr int FRAME_WORDS = LLR_WORDS + 2 * ((16 << (NLOG + 1 - 9)) - 32);
 };
 
+// Decoder of one 1024-leaf subtree.  CHIP (codes longer than 2048): the subtree's own LLRs are stored nowhere.  The
+// level-11 node above it stays on chip instead -- its first half in Ch (element 16 j + lane at Ch[j]), its second half
+// in LDS (hi[64 j], one column per lane) -- and the subtree is that node's left child, LLR j = f(Ch[j], hi[64 j]), or
+// its right child, g of the same pair with the left child's partial sums `lbits`; both top-level steps of the subtree
+// recompute their operands from there.  Not CHIP (N = 2048): Ch holds the subtree's LLRs themselves.
+// Pointers that went through an opaque copy keep their address space in the type, so the accesses stay global_* / ds_*
+// instructions (a generic pointer would make them flat_*, which wait on both memory counters).
+typedef __attribute__((address_space(3))) float lds_float;
+typedef __attribute__((address_space(1))) float glb_float;
+typedef __attribute__((address_space(1))) uint32_t glb_u32;
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) v4f glb_v4f;
+template <bool CHIP> struct BigDec : RegDec<float, 10, 0, false, true> {
+    typedef RegDec<float, 10, 0, false, true> Base;
+    lds_float *hi;
+    uint64_t lbits;
+    bool right;
+    // The operands of one pass over the subtree's LLRs.  They go through an opaque copy on purpose: the pass sits inside
+    // the subtree walk's loops, and loop-invariant code motion would otherwise compute all 64 LLRs (and 64 shifted
+    // partial-sum bits) ahead of the loops and keep them in registers, which is exactly what this layout avoids.
+    struct Operands {
+        const lds_float *hi;
+        uint32_t lo, up;
+    };
+    __device__ __forceinline__ Operands operands() const
+    {
+        Operands o = {hi, (uint32_t)lbits, (uint32_t)(lbits >> 32)};
+        asm volatile("" : "+v"(o.hi), "+v"(o.lo), "+v"(o.up));
+        return o;
+    }
+    template <bool RIGHT> __device__ __forceinline__ float ch(const Operands &o, int j) const
+    {
+        const float a = Ch[j], b = o.hi[64 * j];
+        if constexpr (RIGHT) return g_fast(a, b, ((j < 32 ? o.lo : o.up) >> (j & 31)) & 1u);
+        else return f_fast(a, b);
+    }
+    template <bool IS_G, bool RIGHT> __device__ __forceinline__ void top()
+    {
+        const Operands o = operands();
+#pragma unroll
+        for (int j = 0; j < 32; j++) {
+            const float x = ch<RIGHT>(o, j), y = ch<RIGHT>(o, j + 32);
+            if constexpr (IS_G) R[32 + j] = g_fast(x, y, (uint32_t)(ps0 >> (32 + j)) & 1u);
+            else R[32 + j] = f_fast(x, y);
+        }
+    }
+    template <int LEV, bool IS_G> __device__ __forceinline__ void step(const float *chan_lane)
+    {
+        if constexpr (CHIP && LEV == 10) {
+            if (right) top<IS_G, true>();
+            else top<IS_G, false>();
+        } else {
+            Base::template step<LEV, IS_G>(chan_lane);
+        }
+    }
+};
+
 template <int NLOG> struct BigCtx {
-    RegDec<float, 10, 0, false, true> d;  // the subtree's 1024 LLRs arrive in registers (d.Ch)
+    static constexpr bool CHIP = NLOG > 11;
+    static constexpr int FLOOR = CHIP ? 11 : 10;  // the lowest level a step above the subtrees writes
+    BigDec<CHIP> d;
     RowConst rc;
     BigTables t;
     float *slab;          // this frame's slab
@@ -56,24 +123,28 @@ template <int NLOG> struct BigCtx {
     int sub;
 };
 
-// the lane's index / the frame's slab pointer through an opaque copy (see big_step)
+// the lane's index / the frame's slab pointer through an opaque copy (see big_chain)
 __device__ __forceinline__ int opaque_idx(int v)
 {
     asm volatile("" : "+v"(v));
     return v;
 }
-__device__ __forceinline__ float *opaque_ptr(float *p)
+__device__ __forceinline__ glb_float *opaque_ptr(float *p)
 {
-    asm volatile("" : "+v"(p));
-    return p;
+    glb_float *g = (glb_float *)p;
+    asm volatile("" : "+v"(g));
+    return g;
 }
 
-// f / g from level LEV to LEV-1 (LEV >= 11): elements sub + 16 j of the lane's residue, four (j = 4 J .. 4 J + 3) per trip.
-// The channel itself is in natural order (4-byte accesses); every level of the slab is in the order described above;
-// level 10, the LLRs of one 1024-leaf subtree, is never stored: it goes to the registers cx.d.Ch (element 16 j + sub at Ch[j]).
-// FUSE: the step that follows at once, the f from level LEV-1 to LEV-2 of the left child, is done on the way (its
-// operands are trips J and J + trips/2 of this step's results), which saves reading level LEV-1 back.
-template <int LEV, int NLOG, bool IS_G> __device__ __forceinline__ float4 big_trip(BigCtx<NLOG> &cx, const float *slab, const uint32_t *bits, int J, int sq)
+__device__ __forceinline__ float4 f_fast4(const float4 &a, const float4 &b)
+{
+    return make_float4(f_fast(a.x, b.x), f_fast(a.y, b.y), f_fast(a.z, b.z), f_fast(a.w, b.w));
+}
+
+// f / g from level LEV (the channel, or a level >= 12 of the slab) to LEV-1: elements sub + 16 j of the lane's residue,
+// four (j = 4 J .. 4 J + 3) per trip.  The channel itself is in natural order (4-byte accesses); every level of the
+// slab is in the order described above.
+template <int LEV, int NLOG, bool IS_G> __device__ __forceinline__ float4 big_trip(BigCtx<NLOG> &cx, const glb_float *slab, const glb_u32 *bits, int J, int sq)
 {
     typedef BigLayout<NLOG> Lay;
     constexpr int half = 1 << (LEV - 1);
@@ -83,63 +154,90 @@ template <int LEV, int NLOG, bool IS_G> __device__ __forceinline__ float4 big_tr
         a = make_float4(in[0], in[16], in[32], in[48]);
         b = make_float4(in[half], in[half + 16], in[half + 32], in[half + 48]);
     } else {
-        const float *in = slab + Lay::llr_off(LEV) + 64 * J + 4 * sq;
-        a = *reinterpret_cast<const float4 *>(in);
-        b = *reinterpret_cast<const float4 *>(in + half);
+        static_assert(LEV >= 12, "levels below 12 are not read from the slab");
+        const glb_float *in = slab + Lay::llr_off(LEV) + 64 * J + 4 * sq;
+        const v4f va = *(const glb_v4f *)in, vb = *(const glb_v4f *)(in + half);
+        a = make_float4(va.x, va.y, va.z, va.w);
+        b = make_float4(vb.x, vb.y, vb.z, vb.w);
     }
     if (IS_G) {
         const uint32_t w = bits[(J >> 3) * 16] >> ((4 * J) & 31);
         return make_float4(g_fast(a.x, b.x, w & 1u), g_fast(a.y, b.y, (w >> 1) & 1u), g_fast(a.z, b.z, (w >> 2) & 1u),
                            g_fast(a.w, b.w, (w >> 3) & 1u));
     }
-    return make_float4(f_fast(a.x, b.x), f_fast(a.y, b.y), f_fast(a.z, b.z), f_fast(a.w, b.w));
+    return f_fast4(a, b);
 }
-template <int L, int NLOG> __device__ __forceinline__ void big_put(BigCtx<NLOG> &cx, float *slab, int J, const float4 &r, int sq)
+// trip J of level L goes to its home: the slab (L >= 12), the on-chip level 11 (registers for the first half, LDS for
+// the second) or, for N = 2048, the subtree's LLR registers.  For L <= 11 J must be a compile-time constant after unrolling.
+template <int L, int NLOG> __device__ __forceinline__ void big_put(BigCtx<NLOG> &cx, glb_float *slab, int J, const float4 &r, int sq)
 {
     typedef BigLayout<NLOG> Lay;
-    if constexpr (L == 10) {  // J is a compile-time constant here: the loops over level-10 trips are fully unrolled
+    if constexpr (L == 10) {
+        static_assert(!BigCtx<NLOG>::CHIP, "level 10 is stored for N = 2048 only");
         cx.d.Ch[4 * J] = r.x;
         cx.d.Ch[4 * J + 1] = r.y;
         cx.d.Ch[4 * J + 2] = r.z;
         cx.d.Ch[4 * J + 3] = r.w;
+    } else if constexpr (L == 11) {
+        if (J < 16) {
+            cx.d.Ch[4 * J] = r.x;
+            cx.d.Ch[4 * J + 1] = r.y;
+            cx.d.Ch[4 * J + 2] = r.z;
+            cx.d.Ch[4 * J + 3] = r.w;
+        } else {
+            lds_float *h = cx.d.hi + 256 * (J - 16);
+            h[0] = r.x;
+            h[64] = r.y;
+            h[128] = r.z;
+            h[192] = r.w;
+        }
     } else {
-        *reinterpret_cast<float4 *>(slab + Lay::llr_off(L) + 4 * sq + 64 * J) = r;
+        v4f v = {r.x, r.y, r.z, r.w};
+        *(glb_v4f *)(slab + Lay::llr_off(L) + 4 * sq + 64 * J) = v;
     }
 }
-template <int LEV, int NLOG, bool IS_G, bool FUSE> __device__ __forceinline__ void big_step(BigCtx<NLOG> &cx)
+// the f steps that follow at once: level L from pairs (i, i + CNT) of the trips of level L + 1 held in v, and so on down
+template <int L, int NLOG, int CNT, int TM, int W> __device__ __forceinline__ void big_descend(BigCtx<NLOG> &cx, glb_float *slab, float4 (&v)[W], int t, int sq)
+{
+    if constexpr (CNT >= 1) {
+#pragma unroll
+        for (int i = 0; i < CNT; i++) {
+            v[i] = f_fast4(v[i], v[i + CNT]);
+            big_put<L, NLOG>(cx, slab, t + i * TM, v[i], sq);
+        }
+        big_descend<L - 1, NLOG, CNT / 2, TM, W>(cx, slab, v, t, sq);
+    }
+}
+// The step from level LEV to LEV-1 (f, or g with the left sibling's partial sums) together with the D-1 f steps down
+// the left spine that would follow it at once: levels LEV-1 .. LEV-D are written, and none of them is read back for it
+// (trip t of the lowest level needs trips t + i TM of the levels above, which are still in registers).
+template <int LEV, int NLOG, bool IS_G, int D> __device__ __forceinline__ void big_chain(BigCtx<NLOG> &cx)
 {
     typedef BigLayout<NLOG> Lay;
-    constexpr int half = 1 << (LEV - 1);
+    constexpr int M = LEV - D;          // lowest level written
+    constexpr int TM = (1 << M) / 64;   // its trips: four elements per lane and trip
+    constexpr int W = 1 << (D - 1);     // trips of level LEV-1 per trip of level M
+    static_assert(M >= BigCtx<NLOG>::FLOOR && D >= 1 && D <= 3, "chain depth");
     // the lane's index goes through an opaque copy: addresses derived from it are formed here, base plus instruction
     // offset, instead of being hoisted out of the frame loop as one register pair per access
     int sq = cx.sub;
     asm volatile("" : "+v"(sq));
-    float *slab = opaque_ptr(cx.slab);
-    const uint32_t *bits = reinterpret_cast<const uint32_t *>(slab) + Lay::ps_off(LEV - 1, 0) + sq;
-    constexpr int trips = half / 64;  // four elements per lane and trip
-    if constexpr (!FUSE) {
-        if constexpr (LEV - 1 == 10) {
+    glb_float *slab = opaque_ptr(cx.slab);
+    const glb_u32 *bits = (const glb_u32 *)slab + Lay::ps_off(LEV - 1, 0) + sq;
+    auto body = [&](int t) {
+        float4 v[W];
 #pragma unroll
-            for (int J = 0; J < trips; J++) big_put<LEV - 1, NLOG>(cx, slab, J, big_trip<LEV, NLOG, IS_G>(cx, slab, bits, J, sq), sq);
-        } else {
-#pragma unroll 4
-            for (int J = 0; J < trips; J++) big_put<LEV - 1, NLOG>(cx, slab, J, big_trip<LEV, NLOG, IS_G>(cx, slab, bits, J, sq), sq);
-        }
+        for (int i = 0; i < W; i++) v[i] = big_trip<LEV, NLOG, IS_G>(cx, slab, bits, t + i * TM, sq);
+#pragma unroll
+        for (int i = 0; i < W; i++) big_put<LEV - 1, NLOG>(cx, slab, t + i * TM, v[i], sq);
+        big_descend<LEV - 2, NLOG, W / 2, TM, W>(cx, slab, v, t, sq);
+    };
+    if constexpr (M <= 11) {
+#pragma unroll
+        for (int t = 0; t < TM; t++) body(t);
     } else {
-        static_assert(!FUSE || LEV >= 12, "the fused f writes level LEV-2 >= 10");
-        auto body = [&](int J) {
-            const float4 r1 = big_trip<LEV, NLOG, IS_G>(cx, slab, bits, J, sq), r2 = big_trip<LEV, NLOG, IS_G>(cx, slab, bits, J + trips / 2, sq);
-            big_put<LEV - 1, NLOG>(cx, slab, J, r1, sq);
-            big_put<LEV - 1, NLOG>(cx, slab, J + trips / 2, r2, sq);
-            big_put<LEV - 2, NLOG>(cx, slab, J, make_float4(f_fast(r1.x, r2.x), f_fast(r1.y, r2.y), f_fast(r1.z, r2.z), f_fast(r1.w, r2.w)), sq);
-        };
-        if constexpr (LEV - 2 == 10) {
-#pragma unroll
-            for (int J = 0; J < trips / 2; J++) body(J);
-        } else {
 #pragma unroll 2
-            for (int J = 0; J < trips / 2; J++) body(J);
-        }
+        for (int t = 0; t < TM; t++) body(t);
     }
 }
 
@@ -147,40 +245,64 @@ template <int LEV, int NLOG, bool IS_G, bool FUSE> __device__ __forceinline__ vo
 template <int L, int NLOG> __device__ __forceinline__ void big_rate0(BigCtx<NLOG> &cx, int plane)
 {
     typedef BigLayout<NLOG> Lay;
-    uint32_t *ps = reinterpret_cast<uint32_t *>(opaque_ptr(cx.slab)) + Lay::ps_off(L, plane) + opaque_idx(cx.sub);
+    glb_u32 *ps = (glb_u32 *)opaque_ptr(cx.slab) + Lay::ps_off(L, plane) + opaque_idx(cx.sub);
     for (int w = 0; w < (1 << (L - 9)); w++) ps[w * 16] = 0u;
 }
 template <int L, int NLOG> __device__ __forceinline__ void big_rate1(BigCtx<NLOG> &cx, int plane)
 {
     typedef BigLayout<NLOG> Lay;
+    constexpr bool CHIP = BigCtx<NLOG>::CHIP;
     const int sq = opaque_idx(cx.sub);
-    float *slab = opaque_ptr(cx.slab);
-    uint32_t *ps = reinterpret_cast<uint32_t *>(slab) + Lay::ps_off(L, plane);
-    if constexpr (L == 10) {  // the subtree's LLRs are in registers
+    glb_float *slab = opaque_ptr(cx.slab);
+    glb_u32 *ps = (glb_u32 *)slab + Lay::ps_off(L, plane);
+    if constexpr (L == 10) {
 #pragma unroll
         for (int w = 0; w < 2; w++) {
             uint32_t x = 0;
+            if constexpr (CHIP) {
+                const auto o = cx.d.operands();
+                if (cx.d.right) {
 #pragma unroll
-            for (int i = 0; i < 32; i++) x |= (cx.d.Ch[32 * w + i] < 0.0f ? 1u : 0u) << i;
+                    for (int i = 0; i < 32; i++) x |= (cx.d.template ch<true>(o, 32 * w + i) < 0.0f ? 1u : 0u) << i;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 32; i++) x |= (cx.d.template ch<false>(o, 32 * w + i) < 0.0f ? 1u : 0u) << i;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 32; i++) x |= (cx.d.Ch[32 * w + i] < 0.0f ? 1u : 0u) << i;
+            }
             ps[w * 16 + sq] = x;
         }
-        return;
-    }
-    const float *v = slab + Lay::llr_off(L);
-    for (int w = 0; w < (1 << (L - 9)); w++) {
-        uint32_t x = 0;
+    } else if constexpr (L == 11 && CHIP) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int i = 0; i < 32; i++) {
+                const int q = 32 * w + i;
+                const float v = q < 64 ? cx.d.Ch[q < 64 ? q : 0] : cx.d.hi[64 * (q < 64 ? 0 : q - 64)];
+                x |= (v < 0.0f ? 1u : 0u) << i;
+            }
+            ps[w * 16 + sq] = x;
+        }
+    } else {
+        const glb_float *v = slab + Lay::llr_off(L);
+        for (int w = 0; w < (1 << (L - 9)); w++) {
+            uint32_t x = 0;
 #pragma unroll 8
-        for (int i = 0; i < 32; i++) x |= (v[64 * ((32 * w + i) >> 2) + 4 * sq + (i & 3)] < 0.0f ? 1u : 0u) << i;
-        ps[w * 16 + sq] = x;
+            for (int i = 0; i < 32; i++) x |= (v[64 * ((32 * w + i) >> 2) + 4 * sq + (i & 3)] < 0.0f ? 1u : 0u) << i;
+            ps[w * 16 + sq] = x;
+        }
     }
 }
 // parent (level LEV, plane) = [xl ^ xr, xr] of its children (level LEV-1, planes 0 and 1): whole words per lane
 template <int LEV, int NLOG> __device__ __forceinline__ void big_combine(BigCtx<NLOG> &cx, int plane)
 {
     typedef BigLayout<NLOG> Lay;
-    uint32_t *base = reinterpret_cast<uint32_t *>(opaque_ptr(cx.slab)) + opaque_idx(cx.sub);
-    const uint32_t *xl = base + Lay::ps_off(LEV - 1, 0), *xr = base + Lay::ps_off(LEV - 1, 1);
-    uint32_t *x = base + Lay::ps_off(LEV, plane);
+    glb_u32 *base = (glb_u32 *)opaque_ptr(cx.slab) + opaque_idx(cx.sub);
+    const glb_u32 *xl = base + Lay::ps_off(LEV - 1, 0), *xr = base + Lay::ps_off(LEV - 1, 1);
+    glb_u32 *x = base + Lay::ps_off(LEV, plane);
     constexpr int nw = 1 << (LEV - 10);  // words per lane of a child
     for (int w = 0; w < nw; w++) {
         const uint32_t l = xl[w * 16], r = xr[w * 16];
@@ -189,11 +311,42 @@ template <int LEV, int NLOG> __device__ __forceinline__ void big_combine(BigCtx<
     }
 }
 
+// the step into child cidx of a node of level LEV with as many of the f steps down the child's left spine as apply:
+// the spine node must be a mixed one and its left child not all-frozen.  Returns the number of levels written.
+template <int LEV, int NLOG, bool IS_G> __device__ __forceinline__ int big_step(BigCtx<NLOG> &cx, uint32_t cidx, bool mixed)
+{
+    constexpr int DMAX = (LEV - BigCtx<NLOG>::FLOOR) < 3 ? (LEV - BigCtx<NLOG>::FLOOR) : 3;
+    int D = 1;
+#pragma unroll
+    for (int k = 1; k < DMAX; k++) {
+        // spine node of level LEV-k (the child itself for k = 1) and its left child
+        const uint32_t si = cidx << (k - 1);
+        const bool s_mixed = k == 1 ? mixed : !(((cx.t.up_r0[LEV - k - 10] | cx.t.up_r1[LEV - k - 10]) >> si) & 1ull);
+        const bool left_frozen = (cx.t.up_r0[LEV - k - 1 - 10] >> (2 * si)) & 1ull;
+        if (D == k && s_mixed && !left_frozen) D = k + 1;
+    }
+    if constexpr (DMAX >= 3) {
+        if (D == 3) {
+            big_chain<LEV, NLOG, IS_G, 3>(cx);
+            return 3;
+        }
+    }
+    if constexpr (DMAX >= 2) {
+        if (D == 2) {
+            big_chain<LEV, NLOG, IS_G, 2>(cx);
+            return 2;
+        }
+    }
+    big_chain<LEV, NLOG, IS_G, 1>(cx);
+    return 1;
+}
+
 // node idx of level LEV >= 11, not all-frozen and not all-information; a two-trip loop over the children as in decode_node.
-// have_f: the caller's step has already produced the LLRs of this node's left child (fused f).
-template <int LEV, int NLOG> __device__ __forceinline__ void big_node(BigCtx<NLOG> &cx, uint32_t idx, int plane, bool have_f)
+// have: how many levels of LLRs down this node's left spine (left child, its left child, ...) are there already.
+template <int LEV, int NLOG> __device__ __forceinline__ void big_node(BigCtx<NLOG> &cx, uint32_t idx, int plane, int have)
 {
     typedef BigLayout<NLOG> Lay;
+    constexpr bool CHIP = BigCtx<NLOG>::CHIP;
 #pragma nounroll
     for (uint32_t h = 0; h < 2; h++) {
         const uint32_t cidx = 2 * idx + h;
@@ -203,61 +356,61 @@ template <int LEV, int NLOG> __device__ __forceinline__ void big_node(BigCtx<NLO
             big_rate0<LEV - 1, NLOG>(cx, (int)h);  // an all-frozen child needs no LLRs
             continue;
         }
-        // the child's own first step, the f for its left child, rides along when the child is a mixed node above the
-        // subtrees and that left child is not all-frozen
-        bool fuse = false;
-        if constexpr (LEV >= 12) fuse = !is1 && !((cx.t.up_r0[LEV - 2 - 10] >> (2 * cidx)) & 1ull);
-        if (h == 0) {
-            if (!have_f) {
-                if constexpr (LEV >= 12) {
-                    if (fuse) big_step<LEV, NLOG, false, true>(cx);
-                    else big_step<LEV, NLOG, false, false>(cx);
-                } else {
-                    big_step<LEV, NLOG, false, false>(cx);
-                }
-            } else if constexpr (LEV >= 12) {
-                // level LEV-1 is there already; the grandchild's f still has to be done by the child itself
-                fuse = false;
+        int child_have = 0;
+        if constexpr (CHIP && LEV == 11) {
+            // the child's LLRs are made from this node's, which are on chip, whenever they are needed
+            cx.d.right = h != 0;
+            if (h) {
+                const glb_u32 *ps = (const glb_u32 *)opaque_ptr(cx.slab) + Lay::ps_off(10, 0) + opaque_idx(cx.sub);
+                cx.d.lbits = (uint64_t)ps[0] | ((uint64_t)ps[16] << 32);
             }
         } else {
-            if constexpr (LEV >= 12) {
-                if (fuse) big_step<LEV, NLOG, true, true>(cx);
-                else big_step<LEV, NLOG, true, false>(cx);
-            } else {
-                big_step<LEV, NLOG, true, false>(cx);
-            }
+            if (h == 0 && have > 0) child_have = have - 1;
+            else if (h == 0) child_have = big_step<LEV, NLOG, false>(cx, cidx, !is1) - 1;
+            else child_have = big_step<LEV, NLOG, true>(cx, cidx, !is1) - 1;
         }
         if (is1) {
             big_rate1<LEV - 1, NLOG>(cx, (int)h);
         } else if constexpr (LEV - 1 == 10) {
-            // one 1024-leaf subtree in registers: its LLRs are in cx.d.Ch
+            // one 1024-leaf subtree in registers
             const int lane = (int)threadIdx.x;
             const uint32_t maskv = cx.t.maskw[32 * cidx + (lane & 31)];
             const uint32_t pidv = cx.t.pid16[64 * cidx + lane];
             const NodeClasses nc = cx.t.sub[cidx];
             cx.d.ps0 = cx.d.ps1 = 0;
             cx.d.root = 0;
+#ifndef POLAR_BIG_SKIP_WALK  // timing experiment: everything but the subtree walks (results are wrong then)
             decode_node<10, 10, true>(cx.d, nc, maskv, pidv, nullptr, 0u, 0, cx.rc);
-            uint32_t *ps = reinterpret_cast<uint32_t *>(opaque_ptr(cx.slab)) + Lay::ps_off(10, (int)h) + opaque_idx(cx.sub);
+#else
+            cx.d.root = (uint64_t)(maskv ^ pidv ^ nc.r0[0]) | ((uint64_t)__float_as_uint(cx.d.Ch[0] + cx.d.Ch[63]) << 32);
+#endif
+            glb_u32 *ps = (glb_u32 *)opaque_ptr(cx.slab) + Lay::ps_off(10, (int)h) + opaque_idx(cx.sub);
             ps[0] = (uint32_t)cx.d.root;
             ps[16] = (uint32_t)(cx.d.root >> 32);
         } else {
-            big_node<LEV - 1, NLOG>(cx, cidx, (int)h, fuse);
+            big_node<LEV - 1, NLOG>(cx, cidx, (int)h, child_have);
         }
     }
     big_combine<LEV, NLOG>(cx, plane);
 }
 
+#ifndef POLAR_BIG_MINWAVES
+#define POLAR_BIG_MINWAVES 2  // wavefronts per SIMD the register allocation aims for
+#endif
 template <int NLOG>
-__global__ void __launch_bounds__(64, 3) sc_big_kernel(const float *__restrict__ llr, BigTables t, float *__restrict__ slabs,
+__global__ void __launch_bounds__(64, POLAR_BIG_MINWAVES) sc_big_kernel(const float *__restrict__ llr, BigTables t, float *__restrict__ slabs,
                                                     uint32_t *__restrict__ info_hat, int64_t B, int K, int Kw)
 {
     typedef BigLayout<NLOG> Lay;
     constexpr int N = 1 << NLOG;
     const int lane = threadIdx.x, grp = lane >> 4, sub = lane & 15;
+    __shared__ float hi_lds[BigCtx<NLOG>::CHIP ? 64 * 64 : 1];  // second half of the level-11 node, one column per lane
     BigCtx<NLOG> cx;
     cx.t = t;
     cx.sub = sub;
+    cx.d.hi = (lds_float *)hi_lds + (BigCtx<NLOG>::CHIP ? lane : 0);
+    cx.d.right = false;
+    cx.d.lbits = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         cx.rc.up[i] = (sub & (8 >> i)) != 0;
@@ -270,7 +423,7 @@ __global__ void __launch_bounds__(64, 3) sc_big_kernel(const float *__restrict__
         const bool active = f < B;
         const int64_t fc = active ? f : B - 1;
         cx.chan = llr + fc * N;
-        big_node<NLOG, NLOG>(cx, 0u, 0, false);
+        big_node<NLOG, NLOG>(cx, 0u, 0, 0);
 
         // u_hat = x_hat F^{(x)n} on the sliced root (bit j of lane s = element 16 j + s; 2^(NLOG-9) words per lane)
         uint32_t *x = reinterpret_cast<uint32_t *>(cx.slab) + Lay::ps_off(NLOG, 0);
