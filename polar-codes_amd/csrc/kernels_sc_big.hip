@@ -112,6 +112,15 @@ template <bool CHIP> struct BigDec : RegDec<float, 10, 0, false, true> {
     }
 };
 
+// Channel and slab levels are streams: every value is read once per pass and, in the slab, long after it was written.
+#ifdef POLAR_BIG_NT
+#define BIG_LD(p) __builtin_nontemporal_load(p)
+#define BIG_ST(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define BIG_LD(p) (*(p))
+#define BIG_ST(v, p) (*(p) = (v))
+#endif
+
 template <int NLOG> struct BigCtx {
     static constexpr bool CHIP = NLOG > 11;
     static constexpr int FLOOR = CHIP ? 11 : 10;  // the lowest level a step above the subtrees writes
@@ -151,12 +160,12 @@ template <int LEV, int NLOG, bool IS_G> __device__ __forceinline__ float4 big_tr
     float4 a, b;
     if constexpr (LEV == NLOG) {
         const float *in = cx.chan + 64 * J + sq;
-        a = make_float4(in[0], in[16], in[32], in[48]);
-        b = make_float4(in[half], in[half + 16], in[half + 32], in[half + 48]);
+        a = make_float4(BIG_LD(in), BIG_LD(in + 16), BIG_LD(in + 32), BIG_LD(in + 48));
+        b = make_float4(BIG_LD(in + half), BIG_LD(in + half + 16), BIG_LD(in + half + 32), BIG_LD(in + half + 48));
     } else {
         static_assert(LEV >= 12, "levels below 12 are not read from the slab");
         const glb_float *in = slab + Lay::llr_off(LEV) + 64 * J + 4 * sq;
-        const v4f va = *(const glb_v4f *)in, vb = *(const glb_v4f *)(in + half);
+        const v4f va = BIG_LD((const glb_v4f *)in), vb = BIG_LD((const glb_v4f *)(in + half));
         a = make_float4(va.x, va.y, va.z, va.w);
         b = make_float4(vb.x, vb.y, vb.z, vb.w);
     }
@@ -193,7 +202,7 @@ template <int L, int NLOG> __device__ __forceinline__ void big_put(BigCtx<NLOG> 
         }
     } else {
         v4f v = {r.x, r.y, r.z, r.w};
-        *(glb_v4f *)(slab + Lay::llr_off(L) + 4 * sq + 64 * J) = v;
+        BIG_ST(v, (glb_v4f *)(slab + Lay::llr_off(L) + 4 * sq + 64 * J));
     }
 }
 // the f steps that follow at once: level L from pairs (i, i + CNT) of the trips of level L + 1 held in v, and so on down
