@@ -27,42 +27,7 @@
 #include "decode_common.h"
 #include "reg_common.h"
 #include "polar_internal.h"
-
-template <typename T> struct PBFParams {
-    const T *llr;
-    const uint32_t *rows;                 // frame index of work item w, or NULL for w itself
-    const unsigned long long *nrows_dev;  // number of work items when rows != NULL
-    unsigned long long *work;             // atomic work counter (zero at launch)
-    const uint32_t *ops;                  // every-leaf schedule (16-leaf nodes as single operations when N >= 32)
-    const uint32_t *A;
-    const uint32_t *crcS;                 // NULL: no CRC test (flip-list mode)
-    const int32_t *S0;                    // level-0 candidates (critical set)
-    const int32_t *crit_off;              // CSR over code positions: candidates after a flip at position i
-    const int32_t *crit_idx;
-    const double *sqrt_mu;
-    const int32_t *flips_in;              // [B x 3] fixed flip lists (flip-list mode), or NULL
-    uint32_t *info_hat;                   // [B x Kw]
-    uint32_t *u_hat;                      // [B x Nw] or NULL
-    T *dec_llr;                           // [B x N] or NULL
-    int32_t *runs;                        // [B] or NULL
-    uint8_t *crc_ok;                      // [B] or NULL
-    int32_t *last_seq;                    // [B x 3] or NULL
-    // split two-flip search (all NULL otherwise): frames that fail every single flip, their count, their ranked
-    // first-level candidates (nS0 per frame), and per frame the smallest successful pair found so far as
-    // rank of first flip : rank of second flip : first flip : second flip, 16 bits each (all ones = none)
-    uint32_t *rows2;
-    unsigned long long *nrows2;
-    uint16_t *order_rec;
-    unsigned long long *best;
-    int64_t B;
-    int N, n, Nw, K, Kw, nS0, maxS, max_level;
-};
-
-__device__ __forceinline__ uint32_t wave_xor(uint32_t v)
-{
-    for (int off = 1; off < 64; off <<= 1) v ^= (uint32_t)__shfl_xor((int)v, off, 64);
-    return v;
-}
+#include "kernels_pbf.h"
 
 // The state of one wavefront: LDS areas, the frame it works on, one SC run with flips, candidate ranking.
 template <typename T> struct PBFWave {
@@ -362,11 +327,6 @@ template <typename T> __global__ void __launch_bounds__(64) pbf_decode_kernel(PB
     }
 }
 
-__device__ __forceinline__ unsigned long long load_best(const unsigned long long *a)
-{
-    return __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // Second level of the split search.  Work item w = (first flip's rank a = w / frames, frame slot = w % frames): all
 // frames' most likely first flips come first, and an item whose frame already has a success at a lower rank is
 // dropped without a run.  An item is one interior run (first flip alone, for the decision LLRs that rank the second
@@ -494,6 +454,10 @@ __global__ void __launch_bounds__(256) crc_filter_kernel(const uint32_t *__restr
     }
 }
 
+bool pbf_reg_supported(const polar_code *c, const uint32_t *rows, const int32_t *flips_in, int max_level, bool crc, const void *u_hat,
+                       const void *dec_llr, const PbfSplit *split);
+template <typename T> int launch_pbf_reg(polar_code *c, PBFParams<T> &p, int64_t B, const PbfSplit *split, int max_level);
+
 template <typename T>
 static int launch_pbf_t(polar_code *c, const void *llr, const uint32_t *rows, const unsigned long long *nrows_dev,
                         unsigned long long *work, const int32_t *flips_in, int max_level, bool crc, uint32_t *info_hat,
@@ -533,6 +497,7 @@ static int launch_pbf_t(polar_code *c, const void *llr, const uint32_t *rows, co
     p.nS0 = c->nS0;
     p.maxS = std::max(c->maxS, 1);
     p.max_level = split ? 1 : max_level;
+    if (pbf_reg_supported(c, rows, flips_in, max_level, crc, u_hat, dec_llr, split)) return launch_pbf_reg<T>(c, p, B, split, max_level);
     size_t lds = (size_t)2 * c->N * sizeof(T) + (size_t)p.maxS * 8 + (size_t)4 * c->Nw * 4 + (size_t)c->Kw * 4 + 4 + (size_t)3 * p.maxS * 2;
     lds = (lds + 15) & ~(size_t)15;
     if (lds > 160 * 1024) {

@@ -423,14 +423,12 @@ __device__ __forceinline__ void err_acc_flush(const ErrAcc &a, unsigned long lon
     }
 }
 
-// truth (packed [B x Kw], or NULL): the transmitted information words; their first nbits bits are compared with the
-// decoded ones and the result goes into acc.  info_hat may then be NULL (nothing is stored).  With truth_regs the
-// transmitted words are in tr_lo / tr_hi (lane sub of the frame's row: words sub and sub + 16).
+// First half of the output stage: u_hat of the four frames staged in LDS (sliced), then the information words the
+// lane is responsible for (words sub and sub + 16 of its frame).  The caller synchronises the wavefront before the
+// stage is written again.
 template <int NLOG>
-__device__ __forceinline__ void sc_reg_epilogue(ps_t root, uint32_t *stage, const uint16_t *Asl, uint32_t *__restrict__ info_hat,
-                                                int64_t fc, bool active, int lane, int K, int Kw,
-                                                const uint32_t *__restrict__ truth = nullptr, int nbits = 0, ErrAcc *acc = nullptr,
-                                                bool truth_regs = false, uint32_t tr_lo = 0u, uint32_t tr_hi = 0u)
+__device__ __forceinline__ void sc_reg_words(ps_t root, uint32_t *stage, const uint16_t *Asl, int lane, int K, int Kw, bool gather_words,
+                                             uint32_t &w_lo, uint32_t &w_hi)
 {
     const int grp = lane >> 4, sub = lane & 15;
     uint32_t lo = (uint32_t)root, hi = (uint32_t)(root >> 32);
@@ -442,7 +440,8 @@ __device__ __forceinline__ void sc_reg_epilogue(ps_t root, uint32_t *stage, cons
         if constexpr (NLOG > 9) stage[16 * sub + 8 + grp] = hi;
     }
     wave_sync();
-    if (info_hat || truth || truth_regs) {
+    w_lo = w_hi = 0u;
+    if (gather_words) {
         constexpr int TW = GatherShape<NLOG>::TW;
         const unsigned char *base = reinterpret_cast<const unsigned char *>(stage);
         const uint32_t goff = (uint32_t)grp << 2, wordmask = vgpr_const(~31u);
@@ -458,8 +457,24 @@ __device__ __forceinline__ void sc_reg_epilogue(ps_t root, uint32_t *stage, cons
             const int valid = K - 32 * w;  // unused table entries point at bit 0 of the slice
             return acc & (valid >= 32 ? 0xFFFFFFFFu : (valid <= 0 ? 0u : ((1u << valid) - 1u)));
         };
-        const uint32_t w_lo = gather(sub);
-        const uint32_t w_hi = (TW > 16 && Kw > 16) ? gather(sub + 16) : 0u;
+        w_lo = gather(sub);
+        w_hi = (TW > 16 && Kw > 16) ? gather(sub + 16) : 0u;
+    }
+}
+
+// truth (packed [B x Kw], or NULL): the transmitted information words; their first nbits bits are compared with the
+// decoded ones and the result goes into acc.  info_hat may then be NULL (nothing is stored).  With truth_regs the
+// transmitted words are in tr_lo / tr_hi (lane sub of the frame's row: words sub and sub + 16).
+template <int NLOG>
+__device__ __forceinline__ void sc_reg_epilogue(ps_t root, uint32_t *stage, const uint16_t *Asl, uint32_t *__restrict__ info_hat,
+                                                int64_t fc, bool active, int lane, int K, int Kw,
+                                                const uint32_t *__restrict__ truth = nullptr, int nbits = 0, ErrAcc *acc = nullptr,
+                                                bool truth_regs = false, uint32_t tr_lo = 0u, uint32_t tr_hi = 0u)
+{
+    const int sub = lane & 15;
+    uint32_t w_lo, w_hi;
+    sc_reg_words<NLOG>(root, stage, Asl, lane, K, Kw, info_hat || truth || truth_regs, w_lo, w_hi);
+    if (info_hat || truth || truth_regs) {
         if (info_hat && active) {
             uint32_t *dst = info_hat + fc * Kw;
             if (sub < Kw) dst[sub] = w_lo;

@@ -209,6 +209,46 @@ def test_gpu_pbf_two_flips_in_pieces_equals_whole_frame_search(N, K, poly, nfr, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,K,poly,T,nfr,snr,dtype", [(32, 20, 0x107, 1, 3000, 1.0, 0), (32, 20, 0x107, 2, 2000, 1.0, 1), (64, 30, 0x107, 2, 2000, 1.0, 0),
+                                                       (512, 280, 0x1800063, 1, 3000, 1.5, 1), (512, 280, 0x1800063, 2, 3000, 2.0, 0),
+                                                       (1024, 536, 0x1800063, 1, 4000, 1.5, 1)])
+def test_gpu_pbf_register_search_equals_lds_search(N, K, poly, T, nfr, snr, dtype, monkeypatch):
+    """The search with its SC runs in registers (four candidates per wavefront) against the LDS-staged search with one
+    run per wavefront: runs, flips, CRC flags and bits, every length the register kernel serves, fp32 and fp64."""
+    import torch
+
+    mask, mu = pcf.degaBuild(N, K, 2.0), pcf.GA(N, K, 2.0)
+    w = poly.bit_length() - 1
+    n0 = n0_ebn0(snr, (K - w) / N)
+    code = _native.Code(_native.default_ctx(), mask)
+    code.set_crc(poly)
+    code.set_reliability(mu)
+    npdt = np.float64 if dtype else np.float32
+    dev = torch.device("cuda:0")
+    info_t = torch.zeros((nfr, code.Kw), dtype=torch.int32, device=dev)
+    llr_t = torch.empty((nfr, N), dtype=torch.float64 if dtype else torch.float32, device=dev)
+    code.gen_frames_dev(info_t.data_ptr(), llr_t.data_ptr(), npdt, n0, 9, 0, nfr, crc=True)
+
+    def search():
+        hat = torch.zeros((nfr, code.Kw), dtype=torch.int32, device=dev)
+        runs = torch.zeros(nfr, dtype=torch.int32, device=dev)
+        ok = torch.zeros(nfr, dtype=torch.uint8, device=dev)
+        last = torch.zeros((nfr, 3), dtype=torch.int32, device=dev)
+        code.pbf_decode_dev(llr_t.data_ptr(), npdt, T, hat.data_ptr(), nfr, runs_ptr=runs.data_ptr(), ok_ptr=ok.data_ptr(),
+                            last_ptr=last.data_ptr())
+        code.ctx.sync()
+        return hat.cpu().numpy(), runs.cpu().numpy(), ok.cpu().numpy(), last.cpu().numpy(), code.last_launch()["kernel"]
+
+    reg = search()
+    monkeypatch.setenv("POLAR_PBF_KERNEL", "lds")
+    lds = search()
+    assert reg[4].startswith("pbf_reg_kernel") and lds[4].startswith("pbf_decode_kernel")
+    for a, b in zip(reg[:4], lds[:4]):
+        assert np.array_equal(a, b)
+    assert (lds[1] > 1).any() and (lds[2] == 0).any()
+
+
+@pytest.mark.gpu
 def test_gpu_pbf_argument_errors():
     code = _native.Code(_native.default_ctx(), pcf.degaBuild(64, 32, 2.0))
     llr = np.ones((2, 64), dtype=np.float32)
