@@ -89,7 +89,7 @@ template <bool CHIP> struct BigDec : RegDec<float, 10, 0, false, true> {
     {
         const float a = Ch[j], b = o.hi[64 * j];
         if constexpr (RIGHT) return g_fast(a, b, ((j < 32 ? o.lo : o.up) >> (j & 31)) & 1u);
-        else return f_fast(a, b);
+        else return f_med(a, b);
     }
     template <bool IS_G, bool RIGHT> __device__ __forceinline__ void top()
     {
@@ -98,7 +98,7 @@ template <bool CHIP> struct BigDec : RegDec<float, 10, 0, false, true> {
         for (int j = 0; j < 32; j++) {
             const float x = ch<RIGHT>(o, j), y = ch<RIGHT>(o, j + 32);
             if constexpr (IS_G) R[32 + j] = g_fast(x, y, (uint32_t)(ps0 >> (32 + j)) & 1u);
-            else R[32 + j] = f_fast(x, y);
+            else R[32 + j] = f_med(x, y);
         }
     }
     template <int LEV, bool IS_G> __device__ __forceinline__ void step(const float *chan_lane)
@@ -147,7 +147,7 @@ __device__ __forceinline__ glb_float *opaque_ptr(float *p)
 
 __device__ __forceinline__ float4 f_fast4(const float4 &a, const float4 &b)
 {
-    return make_float4(f_fast(a.x, b.x), f_fast(a.y, b.y), f_fast(a.z, b.z), f_fast(a.w, b.w));
+    return make_float4(f_med(a.x, b.x), f_med(a.y, b.y), f_med(a.z, b.z), f_med(a.w, b.w));
 }
 
 // f / g from level LEV (the channel, or a level >= 12 of the slab) to LEV-1: elements sub + 16 j of the lane's residue,

@@ -50,7 +50,7 @@ template <typename T, int NLOG, int KEEP = 0, bool QUADS = false, bool REGCH = f
 #pragma unroll
             for (int j = 0; j < c; j++) {
                 if constexpr (IS_G) R[c + j] = g_fast(Ch[j], Ch[j + c], (uint32_t)(ps0 >> (c + j)) & 1u);
-                else R[c + j] = f_fast(Ch[j], Ch[j + c]);
+                else R[c + j] = f_med(Ch[j], Ch[j + c]);
             }
             return;
         }
@@ -65,7 +65,7 @@ template <typename T, int NLOG, int KEEP = 0, bool QUADS = false, bool REGCH = f
                 for (int i = 0; i < 4; i++) {
                     const int j = 4 * J + i;
                     if constexpr (IS_G) R[c + j] = g_fast(a[i], b[i], (uint32_t)(ps0 >> (c + j)) & 1u);
-                    else R[c + j] = f_fast(a[i], b[i]);
+                    else R[c + j] = f_med(a[i], b[i]);
                 }
             }
             return;
@@ -90,7 +90,7 @@ template <typename T, int NLOG, int KEEP = 0, bool QUADS = false, bool REGCH = f
                 b = R[3 * c + j];
             }
             if constexpr (IS_G) R[c + j] = g_fast(a, b, (uint32_t)(ps0 >> (c + j)) & 1u);
-            else R[c + j] = f_fast(a, b);
+            else R[c + j] = f_med(a, b);
         }
     }
     template <int LEV> __device__ __forceinline__ void combine(int plane)
@@ -229,7 +229,7 @@ template <int NLOG_, int KEEP = 0, int KL = 0, bool GEN = false> struct StaticDe
                     kept[(2 * (j - KEEP)) * 64] = a4[i];
                     kept[(2 * (j - KEEP) + 1) * 64] = b4[i];
                 }
-                R[c + j] = f_fast(a4[i], b4[i]);
+                R[c + j] = f_med(a4[i], b4[i]);
             }
             // one group at a time: letting the compiler overlap several of them costs more registers than there are
             __builtin_amdgcn_sched_barrier(0);
@@ -301,7 +301,7 @@ template <int NLOG_, int KEEP = 0, int KL = 0, bool GEN = false> struct StaticDe
                     const uint32_t sgn = X[LEV - 5][0] & sg;  // c == 1
                     R[c + j] = b + __uint_as_float(__float_as_uint(a) ^ sgn);
                 } else {
-                    R[c + j] = f_fast(a, b);
+                    R[c + j] = f_med(a, b);
                 }
             }
         }

@@ -222,7 +222,7 @@ template <int NLOG, int LMAX = 8> struct SclReg {
                 }
             }
 #pragma unroll
-            for (int t = 0; t < BT; t++) st_own<LEV - 1>(j0 + t, f_fast(a[t], b[t]), lq);
+            for (int t = 0; t < BT; t++) st_own<LEV - 1>(j0 + t, f_med(a[t], b[t]), lq);
         }
         level_written<LEV - 1>();
         st.ownL = own_set(st.ownL, LEV - 1, (uint32_t)lc.p);

@@ -207,7 +207,7 @@ template <int NLOG, int LMAX> struct WideDec {
                 }
             }
 #pragma unroll
-            for (int t = 0; t < BT; t++) st_own<LEV - 1>(j0 + t, f_fast(a[t], b[t]), lq);
+            for (int t = 0; t < BT; t++) st_own<LEV - 1>(j0 + t, f_med(a[t], b[t]), lq);
         }
         level_written<LEV - 1>();
         own_set<LEV - 1>(oL, (uint32_t)p);

@@ -84,6 +84,16 @@ __device__ __forceinline__ float f_fast(float a, float b)
     return __uint_as_float(and_or(s, vgpr_const(0x80000000u), __float_as_uint(minabs(a, b))));
 }
 __device__ __forceinline__ double f_fast(double a, double b) { return f_minsum(a, b); }
+// The same function in two instructions where both operands are plain registers: the median of (a, -a, b) is
+// sign(b) min(|a|, |b|), and one v_bitop3 gives it the sign of a as well.  (min / max / med3 issue at half rate, so this is
+// three issue slots against four; with a DPP operand v_min_f32_dpp does the fetch for nothing and f_fast stays.)  Only
+// the sign of a zero result can differ from f_fast, which no decision depends on.
+__device__ __forceinline__ float f_med(float a, float b)
+{
+    const float m = __builtin_amdgcn_fmed3f(a, -a, b);
+    return __uint_as_float(__builtin_amdgcn_bitop3_b32(__float_as_uint(a), vgpr_const(0x80000000u), __float_as_uint(m), 0x6A));  // (a & sign) ^ m
+}
+__device__ __forceinline__ double f_med(double a, double b) { return f_minsum(a, b); }
 // b + (bit ? -a : a) with the bit as an integer 0/1
 __device__ __forceinline__ float g_fast(float a, float b, uint32_t bit) { return b + __uint_as_float(__float_as_uint(a) ^ (bit << 31)); }
 __device__ __forceinline__ double g_fast(double a, double b, uint32_t bit) { return g_apply(a, b, bit); }
