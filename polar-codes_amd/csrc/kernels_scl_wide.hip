@@ -1,11 +1,12 @@
 // Register-resident list decoder for long lists: up to L = 32 paths (L = 16 leaves half of the positions empty),
-// N = 64 .. 512, fp32, information bits of the best path: one wavefront per frame, two lanes per path.
+// N = 64 .. 1024, fp32, information bits of the best path: one wavefront per frame, two lanes per path.
 //
 // Lane 2p + h belongs to list position p.  Element k of every tree level of a path lives in the lane with h = k & 1,
 // at index k >> 1, so the partners (k, k + half) of every f and g down to level 2 sit in one lane and are plain
 // register arithmetic; only the 2-leaf nodes exchange values between the two lanes of a path (one DPP swap).
 // Levels 1 .. 6 (63 values per lane) stay in registers, wider levels live lane-major in a slab of global memory
-// per wavefront (N = 512: levels 7 and 8, 48 KB, touched by twelve steps per frame); the channel LLRs, which every
+// per wavefront (N = 512: levels 7 and 8, 48 KB, touched by twelve steps per frame; N = 1024: level 9 as well, 112 KB);
+// the channel LLRs, which every
 // path reads, are staged once per frame in LDS, split by parity.  Partial sums are bit slices in registers.
 //
 // Forking never copies a slice: as in the 8-lanes-per-path kernel (kernels_scl_reg.hip) every path keeps rows of
@@ -79,8 +80,9 @@ template <int NLOG, int LMAX> struct WideDec {
     const float *chs;      // the frame's channel LLRs in LDS, [parity][N/2], + my parity's half
     int lane, p, h;
     // partial sums per plane: a level whose nodes have C bits per lane sits in W[0] at bit offset C for C <= 32, in W[1]
-    // for C = 64, in W[2..3] for C = 128
-    uint64_t A[4], Bp[4], Rt[4];
+    // for C = 64, in W[2..3] for C = 128, in W[4..7] for C = 256; the root (N / 2 bits per lane) fills Rt from bit 0
+    static constexpr int SW = NLOG >= 10 ? 8 : 4;
+    uint64_t A[SW], Bp[SW], Rt[SW];
     float pm;
     uint32_t oL[2], oP[2];  // owner rows, 5 bits per level: levels 1 .. 6 in word 0, from 7 on in word 1; oL[1] bit 31: see node2
     float x;                // my element of the enclosing 2-leaf node's LLRs while its first leaf is decided
@@ -135,29 +137,35 @@ template <int NLOG, int LMAX> struct WideDec {
 
     // ---- bit slices -----------------------------------------------------------------------------------------
     struct Bits {
-        uint64_t w[2];
+        uint64_t w[4];
     };
     template <int C> static __device__ __forceinline__ Bits get_bits(const uint64_t *W)
     {
-        Bits b{{0, 0}};
+        Bits b{{0, 0, 0, 0}};
         if constexpr (C <= 32) b.w[0] = (W[0] >> C) & ((((uint64_t)1) << C) - 1);
         else if constexpr (C == 64) b.w[0] = W[1];
-        else {
+        else if constexpr (C == 128) {
             b.w[0] = W[2];
             b.w[1] = W[3];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) b.w[i] = W[4 + i];
         }
         return b;
     }
     // the C bits of plane-0 level that lanes `src` hold
     template <int C> __device__ __forceinline__ Bits fetch_bits(int src) const
     {
-        Bits b{{0, 0}};
+        Bits b{{0, 0, 0, 0}};
         if constexpr (C <= 16) b.w[0] = (uint64_t)((wb_u((uint32_t)A[0], src) >> C) & ((1u << C) - 1u));
         else if constexpr (C == 32) b.w[0] = (uint64_t)wb_u((uint32_t)(A[0] >> 32), src);
         else if constexpr (C == 64) b.w[0] = wb_u64(A[1], src);
-        else {
+        else if constexpr (C == 128) {
             b.w[0] = wb_u64(A[2], src);
             b.w[1] = wb_u64(A[3], src);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) b.w[i] = wb_u64(A[4 + i], src);
         }
         return b;
     }
@@ -178,11 +186,18 @@ template <int NLOG, int LMAX> struct WideDec {
         } else if constexpr (C == 64) {
             W[root ? 0 : 2] = xl.w[0] ^ xr.w[0];
             W[root ? 1 : 3] = xr.w[0];
-        } else {  // 128 bits per child: the root of N = 512
-            W[0] = xl.w[0] ^ xr.w[0];
-            W[1] = xl.w[1] ^ xr.w[1];
-            W[2] = xr.w[0];
-            W[3] = xr.w[1];
+        } else if constexpr (C == 128) {  // the root of N = 512, or the two level-9 nodes of N = 1024
+            const int o = root ? 0 : 4;
+            W[o] = xl.w[0] ^ xr.w[0];
+            W[o + 1] = xl.w[1] ^ xr.w[1];
+            W[o + 2] = xr.w[0];
+            W[o + 3] = xr.w[1];
+        } else {  // 256 bits per child: the root of N = 1024
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                W[i] = xl.w[i] ^ xr.w[i];
+                W[4 + i] = xr.w[i];
+            }
         }
     }
 
@@ -418,7 +433,7 @@ __global__ void __launch_bounds__(64, 3) scl_wide_kernel(const float *__restrict
             *reinterpret_cast<float2 *>(chan_s + N / 2 + 2 * t) = make_float2(v.y, v.w);
         }
 #pragma unroll
-        for (int i = 0; i < 4; i++) d.A[i] = d.Bp[i] = d.Rt[i] = 0;
+        for (int i = 0; i < Dec::SW; i++) d.A[i] = d.Bp[i] = d.Rt[i] = 0;
         d.pm = 0.0f;
         d.oL[0] = d.oL[1] = d.oP[0] = d.oP[1] = 0u;
         d.x = 0.0f;
@@ -439,22 +454,23 @@ __global__ void __launch_bounds__(64, 3) scl_wide_kernel(const float *__restrict
         }
         wave_sync();
         // its root partial sums (x_hat, lane h holds elements 2j + h) as natural-order words in LDS
-        uint32_t *bw = reinterpret_cast<uint32_t *>(chan_s);  // [2][8] lane streams, then NW words of x_hat / u_hat at +32
+        constexpr int STREAM = 2 * Dec::SW;                   // words per lane stream
+        uint32_t *bw = reinterpret_cast<uint32_t *>(chan_s);  // [2][STREAM] lane streams, then NW words of x_hat / u_hat at +32
         if (act && rank == 0 && d.h == 0) inv[0] = (uint32_t)d.p;
         wave_sync();
         const int best = (int)inv[0];
         if (d.p == best) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                bw[d.h * 8 + 2 * i] = (uint32_t)d.Rt[i];
-                bw[d.h * 8 + 2 * i + 1] = (uint32_t)(d.Rt[i] >> 32);
+            for (int i = 0; i < Dec::SW; i++) {
+                bw[d.h * STREAM + 2 * i] = (uint32_t)d.Rt[i];
+                bw[d.h * STREAM + 2 * i + 1] = (uint32_t)(d.Rt[i] >> 32);
             }
         }
         wave_sync();
         uint32_t *uw = bw + 32;
         if (d.lane < NW) {
             const int w = d.lane;
-            const uint32_t s0 = (bw[w >> 1] >> (16 * (w & 1))) & 0xFFFFu, s1 = (bw[8 + (w >> 1)] >> (16 * (w & 1))) & 0xFFFFu;
+            const uint32_t s0 = (bw[w >> 1] >> (16 * (w & 1))) & 0xFFFFu, s1 = (bw[STREAM + (w >> 1)] >> (16 * (w & 1))) & 0xFFFFu;
             uw[w] = butterfly_word(spread16(s0) | (spread16(s1) << 1), NLOG);
         }
         for (int s = 5; s < NLOG; s++) {
@@ -513,7 +529,7 @@ template <int NLOG> int launch_wide_l(polar_code *c, const void *llr, uint32_t *
 bool scl_wide_supported(const polar_code *c, int dtype, int L, const void *pm, const void *u_hat_all, bool crc, const void *truth)
 {
     if (dtype != POLAR_F32 || (L != 16 && L != 32) || pm || u_hat_all || crc || truth) return false;
-    if (c->n < 6 || c->n > 9 || c->K < 5) return false;
+    if (c->n < 6 || c->n > 10 || c->K < 5) return false;
     const char *e = getenv("POLAR_SCL_KERNEL");
     if (e && e[0] == 'l') return false;  // "lds": force the LDS-staged kernel
     return true;
@@ -527,6 +543,7 @@ int launch_scl_wide(polar_code *c, const void *llr, uint32_t *info_hat, int64_t 
     case 7: return launch_wide_l<7>(c, llr, info_hat, B, L);
     case 8: return launch_wide_l<8>(c, llr, info_hat, B, L);
     case 9: return launch_wide_l<9>(c, llr, info_hat, B, L);
+    case 10: return launch_wide_l<10>(c, llr, info_hat, B, L);
     default: polar_set_error("wide list kernel: unsupported length"); return POLAR_EUNSUPPORTED;
     }
 }

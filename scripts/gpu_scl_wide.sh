@@ -6,7 +6,7 @@ import sys, os; sys.path[:0]=['polar-codes_amd','.']
 import numpy as np, torch, _native, functions as pcf
 from channel import Channel
 ctx=_native.default_ctx(0); ctx.enable_timing(True)
-for (cons,N,K,L,snr,nb) in [('rmpolar',512,256,32,2.0,1<<17),('dega',512,256,32,2.0,1<<17),('dega',512,256,16,2.0,1<<17),('dega',256,128,32,2.0,1<<17),('dega',128,64,32,2.0,1<<17)]:
+for (cons,N,K,L,snr,nb) in [('rmpolar',512,256,32,2.0,1<<17),('dega',512,256,32,2.0,1<<17),('dega',512,256,16,2.0,1<<17),('dega',256,128,32,2.0,1<<17),('dega',128,64,32,2.0,1<<17),('dega',1024,512,32,2.0,1<<16),('dega',1024,512,16,2.0,1<<16)]:
     if os.environ['POLAR_SCL_KERNEL']=='lds': nb >>= 2
     mask = pcf.degaBuild(N,K,2.0) if cons=='dega' else pcf.rmPolarBuild(N,K,2.0)
     code=_native.Code(ctx,mask); n0=Channel('BPSK',snr,'SNRb',K/N).noisePower

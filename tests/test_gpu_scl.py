@@ -192,7 +192,7 @@ def test_scl8_headline_kernel_vs_fp32_oracle(monkeypatch, snr):
 
 @pytest.mark.parametrize("L", [32, 16])
 @pytest.mark.parametrize("cons,N,K", [("dega", 64, 32), ("dega", 128, 64), ("dega", 256, 128), ("dega", 512, 256), ("rmpolar", 512, 256),
-                                      ("dega", 512, 150), ("dega", 256, 200)])
+                                      ("dega", 512, 150), ("dega", 256, 200), ("dega", 1024, 512), ("dega", 1024, 820)])
 def test_scl_wide_kernel_equals_lds_kernel(monkeypatch, cons, N, K, L):
     """The two-lanes-per-path register kernel for lists of 16 and 32 paths against the LDS-staged kernel, which runs the
     same fp32 arithmetic in the same order: identical decoded bits, frame by frame, at an SNR with plenty of close
