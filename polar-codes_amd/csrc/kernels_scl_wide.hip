@@ -1,5 +1,6 @@
 // Register-resident list decoder for long lists: up to L = 32 paths (L = 16 leaves half of the positions empty),
-// N = 64 .. 1024, fp32, information bits of the best path: one wavefront per frame, two lanes per path.
+// N = 64 .. 1024, fp32, information bits of the best path (or of the first path in metric order that passes the CRC /
+// equals the transmitted word): one wavefront per frame, two lanes per path.
 //
 // Lane 2p + h belongs to list position p.  Element k of every tree level of a path lives in the lane with h = k & 1,
 // at index k >> 1, so the partners (k, k + half) of every f and g down to level 2 sit in one lane and are plain
@@ -405,7 +406,8 @@ __device__ __forceinline__ uint32_t spread16(uint32_t v)
 template <int NLOG, int LMAX>
 __global__ void __launch_bounds__(64, 3) scl_wide_kernel(const float *__restrict__ llr, const uint32_t *__restrict__ maskw,
                                                         const uint32_t *__restrict__ Apos, uint32_t *__restrict__ info_hat, int64_t B,
-                                                        int K, int Kw, float *__restrict__ slab)
+                                                        int K, int Kw, float *__restrict__ slab, const uint32_t *__restrict__ crcS,
+                                                        const uint32_t *__restrict__ truth)
 {
     constexpr int N = 1 << NLOG;
     constexpr int NW = N / 32;
@@ -441,7 +443,7 @@ __global__ void __launch_bounds__(64, 3) scl_wide_kernel(const float *__restrict
         wave_sync();
         wide_node<NLOG, NLOG, LMAX>(d, maskv, 0u, 0, keys, inv);
 
-        // the best path: first of the stable descending order of the list
+        // rank of every path in the stable descending order of the list
         const bool act = d.p < d.Lcur;
         const uint32_t key = (act && d.h == 0) ? order_key(d.pm) : 0u;
         keys[d.h ? 32 + d.p : d.p] = key;
@@ -453,48 +455,73 @@ __global__ void __launch_bounds__(64, 3) scl_wide_kernel(const float *__restrict
             rank += (k > key || (k == key && q < d.p)) ? 1 : 0;
         }
         wave_sync();
-        // its root partial sums (x_hat, lane h holds elements 2j + h) as natural-order words in LDS
+        if (act && d.h == 0) inv[rank] = (uint32_t)d.p;  // active paths take the ranks 0 .. Lcur-1
+        wave_sync();
         constexpr int STREAM = 2 * Dec::SW;                   // words per lane stream
         uint32_t *bw = reinterpret_cast<uint32_t *>(chan_s);  // [2][STREAM] lane streams, then NW words of x_hat / u_hat at +32
-        if (act && rank == 0 && d.h == 0) inv[0] = (uint32_t)d.p;
-        wave_sync();
-        const int best = (int)inv[0];
-        if (d.p == best) {
-#pragma unroll
-            for (int i = 0; i < Dec::SW; i++) {
-                bw[d.h * STREAM + 2 * i] = (uint32_t)d.Rt[i];
-                bw[d.h * STREAM + 2 * i + 1] = (uint32_t)(d.Rt[i] >> 32);
-            }
-        }
-        wave_sync();
         uint32_t *uw = bw + 32;
-        if (d.lane < NW) {
-            const int w = d.lane;
-            const uint32_t s0 = (bw[w >> 1] >> (16 * (w & 1))) & 0xFFFFu, s1 = (bw[STREAM + (w >> 1)] >> (16 * (w & 1))) & 0xFFFFu;
-            uw[w] = butterfly_word(spread16(s0) | (spread16(s1) << 1), NLOG);
-        }
-        for (int s = 5; s < NLOG; s++) {
+        // u_hat of the path in list position pos, as natural-order words in LDS: its root partial sums (x_hat, lane h holds
+        // elements 2j + h), then x_hat F^{(x)n}
+        auto path_words = [&](int pos) {
             wave_sync();
-            const int dd = 1 << (s - 5);
-            if (d.lane < NW && !(d.lane & dd)) uw[d.lane] ^= uw[d.lane + dd];
+            if (d.p == pos) {
+#pragma unroll
+                for (int i = 0; i < Dec::SW; i++) {
+                    bw[d.h * STREAM + 2 * i] = (uint32_t)d.Rt[i];
+                    bw[d.h * STREAM + 2 * i + 1] = (uint32_t)(d.Rt[i] >> 32);
+                }
+            }
+            wave_sync();
+            if (d.lane < NW) {
+                const int w = d.lane;
+                const uint32_t s0 = (bw[w >> 1] >> (16 * (w & 1))) & 0xFFFFu, s1 = (bw[STREAM + (w >> 1)] >> (16 * (w & 1))) & 0xFFFFu;
+                uw[w] = butterfly_word(spread16(s0) | (spread16(s1) << 1), NLOG);
+            }
+            for (int s = 5; s < NLOG; s++) {
+                wave_sync();
+                const int dd = 1 << (s - 5);
+                if (d.lane < NW && !(d.lane & dd)) uw[d.lane] ^= uw[d.lane + dd];
+            }
+            wave_sync();
+        };
+        auto info_bit = [&](int k) {
+            const uint32_t pos = Apos[k];
+            return ((uw[pos >> 5] >> (pos & 31)) & 1u) != 0u;
+        };
+        if (crcS || truth) {
+            // aided choice: the first path in metric order that passes, the best one if none does
+            int sel = -1;
+            for (int r = 0; r < d.Lcur && sel < 0; r++) {
+                path_words((int)inv[r]);
+                bool ok;
+                if (truth) {
+                    const uint32_t *tw = truth + f * Kw;
+                    bool differs = false;
+                    pack_bits_group<64>(K, d.lane, 0, info_bit, [&](int wi, uint32_t v) { differs |= (v != tw[wi]); });
+                    ok = !differs;
+                } else {
+                    uint32_t syn = 0u;
+                    for (int k = d.lane; k < K; k += 64)
+                        if (info_bit(k)) syn ^= crcS[k];
+                    for (int off = 1; off < 64; off <<= 1) syn ^= (uint32_t)__shfl_xor((int)syn, off, 64);
+                    ok = syn == 0u;
+                }
+                if (ok) sel = r;
+            }
+            if (sel < 0) path_words((int)inv[0]);
+        } else {
+            path_words((int)inv[0]);
         }
-        wave_sync();
         uint32_t *dst = info_hat + f * Kw;
-        pack_bits_group<64>(
-            K, d.lane, 0,
-            [&](int k) {
-                const uint32_t pos = Apos[k];
-                return ((uw[pos >> 5] >> (pos & 31)) & 1u) != 0u;
-            },
-            [&](int wi, uint32_t v) {
-                if (d.lane == 0) dst[wi] = v;
-            });
+        pack_bits_group<64>(K, d.lane, 0, info_bit, [&](int wi, uint32_t v) {
+            if (d.lane == 0) dst[wi] = v;
+        });
         if (K == 0 && d.lane == 0) dst[0] = 0u;
         wave_sync();
     }
 }
 
-template <int NLOG, int LMAX> int launch_wide_t(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B)
+template <int NLOG, int LMAX> int launch_wide_t(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, bool crc, const uint32_t *truth)
 {
     polar_ctx *ctx = c->ctx;
     auto kern = scl_wide_kernel<NLOG, LMAX>;
@@ -506,7 +533,8 @@ template <int NLOG, int LMAX> int launch_wide_t(polar_code *c, const void *llr, 
     if ((rc = ctx->scl_slab.reserve(std::max<size_t>(4, (size_t)grid * WideStore<NLOG>::MEM_ROWS * 64 * sizeof(float))))) return rc;
     LaunchTimer tm(ctx);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), 0, ctx->stream, (const float *)llr, (const uint32_t *)c->d_maskw,
-                       (const uint32_t *)c->d_A, info_hat, B, c->K, c->Kw, ctx->scl_slab.as<float>());
+                       (const uint32_t *)c->d_A, info_hat, B, c->K, c->Kw, ctx->scl_slab.as<float>(),
+                       crc ? (const uint32_t *)c->d_crcS : (const uint32_t *)nullptr, truth);
     HIP_TRY(hipGetLastError());
     const float ms = tm.stop();
     snprintf(c->last.kernel, sizeof(c->last.kernel), "scl_wide_kernel<%d>/L%d", NLOG, LMAX);
@@ -518,32 +546,32 @@ template <int NLOG, int LMAX> int launch_wide_t(polar_code *c, const void *llr, 
     return POLAR_OK;
 }
 
-template <int NLOG> int launch_wide_l(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, int L)
+template <int NLOG> int launch_wide_l(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, int L, bool crc, const uint32_t *truth)
 {
-    if (L == 32) return launch_wide_t<NLOG, 32>(c, llr, info_hat, B);
-    return launch_wide_t<NLOG, 16>(c, llr, info_hat, B);
+    if (L == 32) return launch_wide_t<NLOG, 32>(c, llr, info_hat, B, crc, truth);
+    return launch_wide_t<NLOG, 16>(c, llr, info_hat, B, crc, truth);
 }
 
 }  // namespace
 
-bool scl_wide_supported(const polar_code *c, int dtype, int L, const void *pm, const void *u_hat_all, bool crc, const void *truth)
+bool scl_wide_supported(const polar_code *c, int dtype, int L, const void *pm, const void *u_hat_all)
 {
-    if (dtype != POLAR_F32 || (L != 16 && L != 32) || pm || u_hat_all || crc || truth) return false;
+    if (dtype != POLAR_F32 || (L != 16 && L != 32) || pm || u_hat_all) return false;
     if (c->n < 6 || c->n > 10 || c->K < 5) return false;
     const char *e = getenv("POLAR_SCL_KERNEL");
     if (e && e[0] == 'l') return false;  // "lds": force the LDS-staged kernel
     return true;
 }
 
-int launch_scl_wide(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, int L)
+int launch_scl_wide(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, int L, bool crc, const uint32_t *truth)
 {
     if (B == 0) return POLAR_OK;
     switch (c->n) {
-    case 6: return launch_wide_l<6>(c, llr, info_hat, B, L);
-    case 7: return launch_wide_l<7>(c, llr, info_hat, B, L);
-    case 8: return launch_wide_l<8>(c, llr, info_hat, B, L);
-    case 9: return launch_wide_l<9>(c, llr, info_hat, B, L);
-    case 10: return launch_wide_l<10>(c, llr, info_hat, B, L);
+    case 6: return launch_wide_l<6>(c, llr, info_hat, B, L, crc, truth);
+    case 7: return launch_wide_l<7>(c, llr, info_hat, B, L, crc, truth);
+    case 8: return launch_wide_l<8>(c, llr, info_hat, B, L, crc, truth);
+    case 9: return launch_wide_l<9>(c, llr, info_hat, B, L, crc, truth);
+    case 10: return launch_wide_l<10>(c, llr, info_hat, B, L, crc, truth);
     default: polar_set_error("wide list kernel: unsupported length"); return POLAR_EUNSUPPORTED;
     }
 }

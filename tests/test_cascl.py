@@ -182,6 +182,39 @@ def test_gpu_ca_register_kernel_equals_lds_kernel(monkeypatch, N, K, poly):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,K,poly,L", [(256, 128, 0x107, 32), (1024, 536, 0x1800063, 16), (64, 32, 0x1621, 32), (512, 300, 0x107, 16),
+                                          (512, 280, 0x1800063, 32)])
+def test_gpu_ca_wide_kernel_equals_lds_kernel(monkeypatch, N, K, poly, L):
+    """fp32, L = 16 / 32: the two-lanes-per-path register kernel and the LDS-staged kernel make the same CRC-aided
+    choice, and it is the choice the host makes from the LDS kernel's list."""
+    import _native
+
+    mask = pcf.degaBuild(N, K, 2.0)
+    w = poly.bit_length() - 1
+    n0 = n0_ebn0(0.5, (K - w) / N)
+    code = _native.Code(_native.default_ctx(), mask)
+    code.set_crc(poly)
+    B = 2000
+    rs = np.random.RandomState(8)
+    word = pcf.crcEncode(rs.randint(0, 2, size=(B, K - w)), poly)
+    x = oracle.polar_encode(word, mask)
+    llr = code.channel_llr(x, n0, 5, 0, np.float32)
+    a, _, _ = code.scl_decode(llr, L, crc=True)
+    assert code.last_launch()["kernel"].startswith("scl_wide_kernel"), code.last_launch()
+    plain, _, _ = code.scl_decode(llr, L)
+    monkeypatch.setenv("POLAR_SCL_KERNEL", "lds")
+    b, _, uh = code.scl_decode(llr, L, want_list=True, crc=True)
+    assert code.last_launch()["kernel"].startswith("scl_decode_kernel")
+    assert np.array_equal(a, b), int(np.any(a != b, axis=1).sum())
+    assert np.any(a != plain)
+    words = uh[:, :, mask == 1]
+    ok = pcf.crcCheck(words.reshape(-1, K), poly).reshape(B, L)
+    pick = np.where(ok.any(axis=1), ok.argmax(axis=1), 0)
+    assert np.array_equal(b, words[np.arange(B), pick])
+    assert (pick > 0).any() and (~ok.any(axis=1)).any()   # deeper list entries get chosen, and some frames have no passing entry
+
+
+@pytest.mark.gpu
 def test_gpu_gen_frames_crc_and_counting():
     """polar_gen_frames with POLAR_CRC: message bits are those of the CRC-less frame, the tail is their CRC;
     polar_count_errors with POLAR_CRC ignores the CRC bits."""

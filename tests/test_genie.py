@@ -134,6 +134,31 @@ def test_gpu_genie_register_kernel_equals_lds_kernel(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,K,L", [(512, 256, 32), (1024, 512, 16), (128, 64, 32)])
+def test_gpu_genie_wide_kernel_equals_lds_kernel(monkeypatch, N, K, L):
+    import _native
+
+    mask = pcf.degaBuild(N, K, 2.0)
+    n0 = n0_ebn0(0.5, K / N)
+    code = _native.Code(_native.default_ctx(), mask)
+    B = 1500
+    msg = np.random.RandomState(2).randint(0, 2, size=(B, K)).astype(np.uint8)
+    llr = code.channel_llr(oracle.polar_encode(msg, mask), n0, 5, 0, np.float32)
+    a, _, _ = code.scl_decode_genie(llr, L, msg)
+    assert code.last_launch()["kernel"].startswith("scl_wide_kernel"), code.last_launch()
+    plain, _, _ = code.scl_decode(llr, L)
+    monkeypatch.setenv("POLAR_SCL_KERNEL", "lds")
+    b, _, uh = code.scl_decode_genie(llr, L, msg, want_list=True)
+    assert code.last_launch()["kernel"].startswith("scl_decode_kernel")
+    assert np.array_equal(a, b)
+    words = uh[:, :, mask == 1]
+    hit = (words == msg[:, None, :]).all(axis=2)
+    pick = np.where(hit.any(axis=1), hit.argmax(axis=1), 0)
+    assert np.array_equal(b, words[np.arange(B), pick])
+    assert (pick > 0).any() and np.any(a != plain)
+
+
+@pytest.mark.gpu
 def test_gpu_genie_argument_errors():
     import _native
 
