@@ -663,11 +663,25 @@ extern "C" __global__ void __launch_bounds__(64 * SC_STATIC_WAVES, POLAR_STATIC_
         wave_sync();
         uint32_t xlo = stage[16 * sub + grp], xhi = (NLOG > 9) ? stage[16 * sub + 8 + grp] : 0u;
         wave_sync();
+        const uint32_t ulo = xlo, uhi = xhi;   // the transmitted u, sliced: zero at frozen positions
         slice_transform<NLOG>(xlo, xhi, sub);  // u -> x
         d.cg.xlo = xlo;
         d.cg.xhi = xhi;
         decode_static<PolarStaticProfile, NLOG, 0, 0>(d, nullptr, rc);
-        sc_reg_epilogue<NLOG>(d.root, stage, asl_s, nullptr, fc, active, lane, K, Kw, nullptr, K, &acc, true, iw[0], iw[1]);
+        // errors are counted where the decoder's result lies, in the sliced u domain: u_hat is zero at frozen positions as
+        // well, so the differing bits are exactly the wrong information bits and no bit has to be gathered
+        uint32_t hlo = (uint32_t)d.root, hhi = (uint32_t)(d.root >> 32);
+        slice_transform<NLOG>(hlo, hhi, sub);  // x_hat -> u_hat
+        uint32_t e = __popc(hlo ^ ulo) + ((NLOG > 9) ? __popc(hhi ^ uhi) : 0u);
+        e += dpp_mov_u32<0x128>(e);
+        e += dpp_mov_u32<0x124>(e);
+        e += dpp_mov_u32<0x122>(e);
+        e += dpp_mov_u32<0x121>(e);
+        if (active && sub == 0) {
+            acc.be += e;
+            acc.fe += e ? 1u : 0u;
+            acc.fr += 1u;
+        }
     }
     err_acc_flush(acc, counters);
 }
