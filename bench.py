@@ -427,6 +427,7 @@ def main():
         for name, staged in (("mc_fused_sc", False), ("mc_pipeline_sc", True)):
             if staged:
                 os.environ["POLAR_MC_KERNEL"] = "staged"
+                os.environ["POLAR_EXPERIMENT"] = "1"  # the library reads its kernel switches only with this set
             try:
                 code.mc_run(_native.DEC_SC, 1, np.float32, ch.noisePower, seed, 0, (1 << 20) + 4096)  # warm-up, sizes the buffers
                 t0 = time.perf_counter()
@@ -438,6 +439,7 @@ def main():
                     extras[name]["roofline"] = leg_roofline(code.last_launch()["kernel"], mdt * 1e3, nmc, N, K, hbm_bytes_per_frame=0.0)
             finally:
                 os.environ.pop("POLAR_MC_KERNEL", None)
+                os.environ.pop("POLAR_EXPERIMENT", None)
         out["extras"] = extras
 
     if rank == 0 and world == 1 and not a.no_cpu:

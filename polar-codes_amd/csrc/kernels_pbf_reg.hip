@@ -405,7 +405,7 @@ bool pbf_reg_supported(const polar_code *c, const uint32_t *rows, const int32_t 
     if (!rows || flips_in || u_hat || dec_llr || !crc) return false;
     if (c->n < 5 || c->n > 10 || c->K < 1 || c->K > 1024) return false;
     if (!(max_level == 1 || (max_level == 2 && split))) return false;
-    const char *e = getenv("POLAR_PBF_KERNEL");
+    const char *e = polar_switch("POLAR_PBF_KERNEL");
     if (e && e[0] == 'l') return false;  // "lds": the LDS-staged search
     return true;
 }

@@ -249,7 +249,7 @@ template <typename T, int G> __global__ void __launch_bounds__(64) sc_decode_ker
 // ------------------------------------------------------------------------------------------ launch
 static int pick_lanes(int N, size_t elem)
 {
-    const char *e = getenv("POLAR_SC_LANES");
+    const char *e = polar_switch("POLAR_SC_LANES");
     if (e) {
         int g = atoi(e);
         if (g == 8 || g == 16 || g == 32 || g == 64) return g;

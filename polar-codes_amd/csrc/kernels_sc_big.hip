@@ -498,7 +498,7 @@ bool sc_big_supported(const polar_code *c, int dtype, const void *u_hat, const v
     if (dtype != POLAR_F32 || !(flags & POLAR_SC_FAST)) return false;
     if (c->n < 11 || c->n > 16) return false;
     if (c->K == 0 || c->K == c->N) return false;
-    const char *e = getenv("POLAR_SC_KERNEL");
+    const char *e = polar_switch("POLAR_SC_KERNEL");
     if (e && e[0] == 'l') return false;  // "lds": force the LDS-staged kernel
     return true;
 }
@@ -574,7 +574,7 @@ template <int NLOG> static int launch_big_t(polar_code *c, const void *llr, uint
     int occ = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, 0));
     if (occ < 1) occ = 1;
-    if (const char *e = getenv("POLAR_BIG_WAVES")) occ = std::max(1, std::min(occ, atoi(e)));  // experiment: wavefronts per CU
+    if (const char *e = polar_switch("POLAR_BIG_WAVES")) occ = std::max(1, std::min(occ, atoi(e)));  // experiment: wavefronts per CU
     const int64_t need = (B + 3) / 4;
     const int64_t grid = std::min<int64_t>(need, (int64_t)ctx->num_cus * occ);
     if ((rc = ctx->scl_slab.reserve((size_t)grid * 4 * BigLayout<NLOG>::FRAME_WORDS * 4))) return rc;

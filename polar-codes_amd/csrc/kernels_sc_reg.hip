@@ -165,7 +165,7 @@ bool sc_reg_supported(const polar_code *c, int dtype, const void *u_hat, const v
     if (c->n < 5 || c->n > 10) return false;
     if (c->K == 0 || c->K == c->N) return false;  // root would be a rate-0 / rate-1 node
     if (dtype != POLAR_F32) return false;  // fp64 (parity mode) runs on sc_reg_full_kernel or the LDS-staged kernel
-    const char *e = getenv("POLAR_SC_KERNEL");
+    const char *e = polar_switch("POLAR_SC_KERNEL");
     if (e && e[0] == 'l') return false;  // "lds": force the LDS-staged kernel
     return true;
 }
@@ -176,7 +176,7 @@ bool sc_reg_full_supported(const polar_code *c, int dtype, const void *u_hat, co
     if (c->n < 5 || c->n > 10) return false;
     if (dtype == POLAR_F32 && !u_hat && !dec_llr) return false;  // the fp32 information-bit kernels are faster
     if ((flags & POLAR_SC_FAST) && dtype == POLAR_F32) return false;
-    const char *e = getenv("POLAR_SC_KERNEL");
+    const char *e = polar_switch("POLAR_SC_KERNEL");
     if (e && e[0] == 'l') return false;
     return true;
 }
@@ -230,7 +230,7 @@ template <typename T, int NLOG, bool FAST> static int launch_reg_t(polar_code *c
     const NodeClasses nc = classify_nodes(c, FAST);
     auto kern = sc_reg_kernel<T, NLOG, FAST>;
     // POLAR_SC_LDSPAD (bytes of unused dynamic LDS per wavefront) lowers the occupancy for experiments
-    const char *pe = getenv("POLAR_SC_LDSPAD");
+    const char *pe = polar_switch("POLAR_SC_LDSPAD");
     const size_t pad = pe ? (size_t)atoi(pe) : 0;
     if (pad > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
     int occ = 0;
@@ -271,7 +271,7 @@ int launch_sc_reg(polar_code *c, const void *llr, int dtype, uint32_t *info_hat,
 {
     if (B == 0) return POLAR_OK;
     if (c->static_fn && (flags & POLAR_SC_FAST) && dtype == POLAR_F32) {
-        const char *e = getenv("POLAR_SC_KERNEL");
+        const char *e = polar_switch("POLAR_SC_KERNEL");
         if (!(e && e[0] == 'g')) return launch_sc_static(c, llr, info_hat, B);  // "generic": keep the generic kernel
     }
     if (dtype != POLAR_F32) {

@@ -728,7 +728,7 @@ bool scl_reg_supported(const polar_code *c, int dtype, int L, const void *pm, co
 {
     if (dtype != POLAR_F32 || (L != 8 && L != 4 && L != 2) || pm || u_hat_all) return false;
     if (c->n < 6 || c->n > 10 || c->K < 3) return false;
-    const char *e = getenv("POLAR_SCL_KERNEL");
+    const char *e = polar_switch("POLAR_SCL_KERNEL");
     if (e && e[0] == 'l') return false;  // "lds": force the LDS-staged kernel
     return true;
 }
@@ -739,7 +739,7 @@ static int launch_scl_reg_t(polar_code *c, const void *llr, uint32_t *info_hat, 
     polar_ctx *ctx = c->ctx;
     auto kern = scl_reg_kernel<NLOG, LMAX>;
     // POLAR_SCL_LDSPAD (bytes of unused dynamic LDS per wavefront) lowers the occupancy for experiments
-    const char *pe = getenv("POLAR_SCL_LDSPAD");
+    const char *pe = polar_switch("POLAR_SCL_LDSPAD");
     const size_t pad = pe ? (size_t)atoi(pe) : 0;
     if (pad > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
     int occ = 0;

@@ -558,7 +558,7 @@ bool scl_wide_supported(const polar_code *c, int dtype, int L, const void *pm, c
 {
     if (dtype != POLAR_F32 || (L != 16 && L != 32) || pm || u_hat_all) return false;
     if (c->n < 6 || c->n > 10 || c->K < 5) return false;
-    const char *e = getenv("POLAR_SCL_KERNEL");
+    const char *e = polar_switch("POLAR_SCL_KERNEL");
     if (e && e[0] == 'l') return false;  // "lds": force the LDS-staged kernel
     return true;
 }

@@ -669,7 +669,7 @@ static int pbf_device(polar_code *c, const void *dl, int dtype, int max_level, u
     if ((rc = ctx->flip_rows.reserve(nb * 4)) || (rc = ctx->flip_ctr.reserve(32))) return rc;
     uint32_t *rows = ctx->flip_rows.as<uint32_t>();
     unsigned long long *ctr = ctx->flip_ctr.as<unsigned long long>();
-    const char *sw = getenv("POLAR_PBF_SPLIT");
+    const char *sw = polar_switch("POLAR_PBF_SPLIT");
     const bool whole_frames = sw && atoi(sw) == 0;
     if (max_level != 2 || whole_frames) return pbf_device_on(c, dl, dtype, max_level, wi, d_runs, d_ok, d_last, nb, rows, ctr);
     // two flips: the second level is worked on in (frame, first flip) pieces, PBF_SPLIT_FRAMES frames at a time
@@ -916,7 +916,7 @@ extern "C" int polar_sc_decode_count(polar_code *c, const void *llr, int dtype, 
 // double-buffered pipeline with small runs)
 static int64_t mc_chunk_limit(int64_t deflt)
 {
-    if (const char *e = getenv("POLAR_MC_CHUNK")) {
+    if (const char *e = polar_switch("POLAR_MC_CHUNK")) {
         const long long v = atoll(e);
         if (v > 0) return std::min<int64_t>(deflt, (int64_t)v);
     }
@@ -952,7 +952,7 @@ extern "C" int polar_mc_run(polar_code *c, int decoder, int L, int dtype, int fl
     // a code with a specialised decoder runs fp32 SC frames in one kernel, from the random bits to the counters, with no
     // LLR buffer at all (POLAR_MC_KERNEL=staged keeps the generator -> buffer -> decoder pipeline below)
     if (decoder == POLAR_DEC_SC && dtype == POLAR_F32 && (flags & POLAR_SC_FAST) && !crc && c->static_mc_fn) {
-        const char *e = getenv("POLAR_MC_KERNEL");
+        const char *e = polar_switch("POLAR_MC_KERNEL");
         if (!(e && e[0] == 's')) {
             int rc;
             if ((rc = ctx->counters.reserve(3 * sizeof(uint64_t)))) return rc;

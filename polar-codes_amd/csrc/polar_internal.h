@@ -1,5 +1,6 @@
 // Internal declarations shared by the translation units of libpolar_hip.so.
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -139,6 +140,15 @@ int launch_sc_static(polar_code *c, const void *llr, uint32_t *info_hat, int64_t
 int launch_sc_static_mc(polar_code *c, int64_t B, double N0, uint64_t seed, uint64_t frame0, uint64_t *counters_dev);
 
 // timing bracket around the dominant kernel of a call
+// Switches for experiments and for the tests that compare kernels (POLAR_SC_KERNEL, POLAR_SCL_KERNEL, ...): read from the
+// environment only when POLAR_EXPERIMENT=1 is set as well, so that no stray variable changes which kernel a product run uses.
+inline const char *polar_switch(const char *name)
+{
+    const char *on = getenv("POLAR_EXPERIMENT");
+    if (!on || on[0] != '1') return nullptr;
+    return getenv(name);
+}
+
 struct LaunchTimer {
     polar_ctx *ctx;
     explicit LaunchTimer(polar_ctx *c) : ctx(c)

@@ -18,9 +18,9 @@ static int compile_static(const uint8_t *mask, int N, const char *arch, std::vec
     while ((1 << n) < N) n++;
     std::string src;
     // experiment knobs: channel pairs kept in registers / in LDS per lane, and the occupancy the compiler aims for
-    if (const char *e = getenv("POLAR_STATIC_KEEP")) src += "#define POLAR_STATIC_KEEP " + std::to_string(atoi(e)) + "\n";
-    if (const char *e = getenv("POLAR_STATIC_KEEP_LDS")) src += "#define POLAR_STATIC_KEEP_LDS " + std::to_string(atoi(e)) + "\n";
-    if (const char *e = getenv("POLAR_STATIC_WAVES")) src += "#define POLAR_STATIC_WAVES " + std::to_string(atoi(e)) + "\n";
+    if (const char *e = polar_switch("POLAR_STATIC_KEEP")) src += "#define POLAR_STATIC_KEEP " + std::to_string(atoi(e)) + "\n";
+    if (const char *e = polar_switch("POLAR_STATIC_KEEP_LDS")) src += "#define POLAR_STATIC_KEEP_LDS " + std::to_string(atoi(e)) + "\n";
+    if (const char *e = polar_switch("POLAR_STATIC_WAVES")) src += "#define POLAR_STATIC_WAVES " + std::to_string(atoi(e)) + "\n";
     src += "#define POLAR_STATIC_NLOG " + std::to_string(n) + "\n#define POLAR_STATIC_WORDS ";
     for (int w = 0; w < (N + 31) / 32; w++) {
         uint32_t v = 0;
@@ -57,7 +57,7 @@ static int compile_static(const uint8_t *mask, int N, const char *arch, std::vec
     hiprtcGetCode(prog, code.data());
     hiprtcDestroyProgram(&prog);
     // POLAR_STATIC_DUMP=<file>: keep the code object (llvm-objdump -d shows what the specialisation produced)
-    if (const char *e = getenv("POLAR_STATIC_DUMP")) {
+    if (const char *e = polar_switch("POLAR_STATIC_DUMP")) {
         if (FILE *fp = fopen(e, "wb")) {
             fwrite(code.data(), 1, code.size(), fp);
             fclose(fp);

@@ -1,4 +1,5 @@
 # long-code SC kernel at (16384,8192): wavefronts per CU against rate (fewer frames in flight = smaller slab working set)
+export POLAR_EXPERIMENT=1  # the library reads its kernel switches only with this set
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
 for W in 16 12 8 6 4 3 2; do
 POLAR_BIG_WAVES=$W timeout -k 10 200 python3 - <<'PY' || exit 1

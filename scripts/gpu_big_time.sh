@@ -1,4 +1,5 @@
 # long-code SC kernel at (16384,8192): rate only (POLAR_HIP_LIB selects an experimental build)
+export POLAR_EXPERIMENT=1  # the library reads its kernel switches only with this set
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
 timeout -k 10 120 python3 - <<'PY' || exit 1
 import sys, os; sys.path[:0]=['polar-codes_amd','.']

@@ -1,4 +1,5 @@
 # long-code SC kernel at (16384,8192): rate, then HBM traffic per frame (FETCH_SIZE / WRITE_SIZE in separate passes)
+export POLAR_EXPERIMENT=1  # the library reads its kernel switches only with this set
 export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-$PWD}; cd /tmp
 cat > /tmp/big1.py <<PY
 import sys; sys.path[:0]=['$R/polar-codes_amd','$R']

@@ -1,4 +1,5 @@
 # Full GPU check: whole gpu test suite, smoke, bench (JSON), rocprof stats of the bench, PMC traffic passes.
+export POLAR_EXPERIMENT=1  # the library reads its kernel switches only with this set
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; export TMPDIR=/tmp
 timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/tests_gpu.log 2>&1; echo EXIT $? >> gpurun_out/tests_gpu.log; tail -3 gpurun_out/tests_gpu.log

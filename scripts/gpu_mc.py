@@ -1,6 +1,7 @@
 """Monte-Carlo loop: the single fused kernel against generator -> buffer -> decoder (POLAR_MC_KERNEL=staged): counters
 must be identical; frames per second of both."""
 import sys, os, time
+os.environ["POLAR_EXPERIMENT"] = "1"  # the library reads its kernel switches only with this set
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "polar-codes_amd")]
 import numpy as np

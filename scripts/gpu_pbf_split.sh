@@ -1,4 +1,5 @@
 # two-flip search worked on in (frame, first flip) pieces: parity tests, then the rate against one wavefront per frame
+export POLAR_EXPERIMENT=1  # the library reads its kernel switches only with this set
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
 timeout -k 10 500 python -u -m pytest tests/test_flip.py tests/test_zz_no_alloc.py -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/t_flip.log 2>&1 || { tail -30 gpurun_out/t_flip.log; exit 1; }
 tail -2 gpurun_out/t_flip.log

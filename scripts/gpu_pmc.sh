@@ -1,4 +1,5 @@
 # usage: bash scripts/gpu_pmc.sh  -> per-dispatch counters of the SC kernel under gpurun_out/pmc_*
+export POLAR_EXPERIMENT=1  # the library reads its kernel switches only with this set
 export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-$PWD}; cd /tmp
 A="--no-cpu --no-extras --frames 4000000 --steps 1 --warmup 0"
 for P in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_IFETCH GRBM_GUI_ACTIVE" "FETCH_SIZE"; do

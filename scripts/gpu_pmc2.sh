@@ -1,4 +1,5 @@
 # usage: bash scripts/gpu_pmc2.sh  -> latency / branch counters of the SC kernel under gpurun_out/pmc2_*
+export POLAR_EXPERIMENT=1  # the library reads its kernel switches only with this set
 export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-$PWD}; cd /tmp
 A="--no-cpu --no-extras --frames 4000000 --steps 1 --warmup 0"
 for P in "SQ_INSTS_BRANCH SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM SQ_INST_CYCLES_VMEM_RD SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do

@@ -1,5 +1,6 @@
 # HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) and L2 hit / miss of the secondary kernels: the long-code SC kernel
 # at (16384,8192) and the list decoders.  Prints bytes per frame against the algorithmic figure; json in gpurun_out/traffic_legs.json
+export POLAR_EXPERIMENT=1  # the library reads its kernel switches only with this set
 export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-$PWD}; cd /tmp
 cat > /tmp/legs.py <<PY
 import sys; sys.path[:0]=['$R/polar-codes_amd','$R']

@@ -1,5 +1,6 @@
 # rocprof kernel stats, SQ counters and HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) of the secondary kernels:
 # list decoders (L = 8 and L = 32), long-code SC kernel, flip search.  Summaries: gpurun_out/legs_*.{csv,txt,json}
+export POLAR_EXPERIMENT=1  # the library reads its kernel switches only with this set
 export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-$PWD}; cd /tmp
 cat > /tmp/legs.py <<PY
 import sys; sys.path[:0]=['$R/polar-codes_amd','$R']

@@ -1,4 +1,5 @@
 # rocprof stats + SQ counters for the SCL L=8 leg
+export POLAR_EXPERIMENT=1  # the library reads its kernel switches only with this set
 export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-$PWD}; cd /tmp
 cat > /tmp/scl_only.py <<PY
 import sys; sys.path[:0]=['$R/polar-codes_amd','$R']

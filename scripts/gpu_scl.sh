@@ -1,3 +1,4 @@
+export POLAR_EXPERIMENT=1  # the library reads its kernel switches only with this set
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
 timeout -k 10 300 python -u -m pytest tests/test_gpu_scl.py tests/test_gpu_curves.py -m gpu -x -q --timeout 200 --timeout-method thread > gpurun_out/t_scl.log 2>&1; echo EXIT $? >> gpurun_out/t_scl.log; tail -3 gpurun_out/t_scl.log
 timeout -k 10 300 python3 - <<'PY'

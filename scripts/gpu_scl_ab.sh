@@ -1,4 +1,5 @@
 # register list decoder: equality with the LDS kernel, then variants side by side (POLAR_SCL_KERNEL=reg1 is the older form)
+export POLAR_EXPERIMENT=1  # the library reads its kernel switches only with this set
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
 timeout -k 10 400 python -u -m pytest tests/test_gpu_scl.py -m gpu -x -q --timeout 200 --timeout-method thread -k "register_kernel or fp32" > gpurun_out/t_scl_ab.log 2>&1 || { tail -30 gpurun_out/t_scl_ab.log; exit 1; }
 tail -2 gpurun_out/t_scl_ab.log

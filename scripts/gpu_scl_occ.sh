@@ -1,4 +1,5 @@
 # register SCL kernel (L = 8) at 8 (default), 4 and 2 wavefronts per CU: how much of its time is latency
+export POLAR_EXPERIMENT=1  # the library reads its kernel switches only with this set
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
 for PAD in 0 36000 72000; do
 POLAR_SCL_LDSPAD=$PAD timeout -k 10 200 python3 - <<'PY'

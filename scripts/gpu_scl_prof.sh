@@ -1,4 +1,5 @@
 # where the register list decoder spends its time: cycle counters per category (library built with `make prof`)
+export POLAR_EXPERIMENT=1  # the library reads its kernel switches only with this set
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
 for V in ${VARIANTS:-reg1 reg}; do
 POLAR_HIP_LIB=$R/polar-codes_amd/libpolar_hip_prof.so POLAR_SCL_KERNEL=$V timeout -k 10 200 python3 - <<'PY' || exit 1

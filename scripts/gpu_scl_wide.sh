@@ -1,4 +1,5 @@
 # list decoding with 16 / 32 paths: the two-lanes-per-path register kernel against the LDS-staged kernel
+export POLAR_EXPERIMENT=1  # the library reads its kernel switches only with this set
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
 for V in reg lds; do
 POLAR_SCL_KERNEL=$V timeout -k 10 300 python3 - <<'PY' || exit 1

@@ -1,4 +1,5 @@
 # specialised SC decoder: 4-byte channel loads (WIDE 0) against 16-byte loads staged through LDS, frames in flight per group
+export POLAR_EXPERIMENT=1  # the library reads its kernel switches only with this set
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
 timeout -k 10 300 python -u -m pytest tests/test_gpu_sc.py -m gpu -x -q -k "specialised or fused" --timeout 200 --timeout-method thread > gpurun_out/t_static.log 2>&1 || { tail -30 gpurun_out/t_static.log; exit 1; }
 tail -1 gpurun_out/t_static.log

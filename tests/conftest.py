@@ -26,3 +26,10 @@ def golden():
             return z
 
     return G()
+
+
+@pytest.fixture(autouse=True)
+def _kernel_switches_enabled(monkeypatch):
+    """Tests select kernels through the library's experiment switches (POLAR_SC_KERNEL=lds ...), which it reads from the
+    environment only when POLAR_EXPERIMENT=1 is set."""
+    monkeypatch.setenv("POLAR_EXPERIMENT", "1")

@@ -2,6 +2,7 @@
 Usage: python tools/dump_static_isa.py [N K design_snr_db] > isa.s
 """
 import os
+os.environ["POLAR_EXPERIMENT"] = "1"  # the library reads its switches only with this set
 import subprocess
 import sys
 import tempfile
