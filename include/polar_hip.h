@@ -100,6 +100,12 @@ int polar_code_crc_width(const polar_code *code);
  * single in-register operations.  Needs no GPU. */
 int polar_schedule_build(const uint8_t *mask, int N, int fast, uint32_t *out, int cap);
 
+/* Host-only: the 256-word table of the register SC kernels' output stage for `mask` (32 <= N <= 1024): per lane of a
+ * frame's row the masks that compress the information bits of its 16-position pieces and the bit offsets the pieces go to
+ * (polar-codes_amd/csrc/host_tables.h has the layout).  No counterpart in the reference (its extract() is
+ * uHat[polarMask == 1], cn/polarCode.py:305-312); exposed for the CPU tests.  Needs no GPU. */
+int polar_output_tables(const uint8_t *mask, int N, uint32_t *out256);
+
 /* ---- encoder: PolarCode.polarEncode = mul_matrix(rateProfile(info)) (cn/polarCode.py:225-255).
  *      info [B x K] -> x [B x N], x = u F^{(x)n}, natural order, no bit reversal. */
 int polar_encode(polar_code *code, const uint8_t *info, uint8_t *x, int64_t B, int space);

@@ -51,6 +51,7 @@ SIGNATURES = {
     "polar_code_set_crc": (_i, [_vp, _u64]),
     "polar_code_crc_width": (_i, [_vp]),
     "polar_schedule_build": (_i, [_vp, _i, _i, _vp, _i]),
+    "polar_output_tables": (_i, [_vp, _i, _vp]),
     "polar_encode": (_i, [_vp, _vp, _vp, _i64, _i]),
     "polar_encode_packed": (_i, [_vp, _vp, _vp, _i64, _i]),
     "polar_mul_matrix": (_i, [_vp, _vp, _vp, _i64, _i]),
@@ -94,6 +95,8 @@ def lib():
             pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
+            if os.environ.get("POLAR_HIP_LIB") and not hasattr(L, name):
+                continue  # an older build loaded for a side-by-side measurement lacks the newest entry points
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
@@ -372,6 +375,14 @@ def schedule_build(mask, fast, sub16=False):
         _check(n)
     out = np.empty(n, dtype=np.uint32)
     _check(min(0, lib().polar_schedule_build(m.ctypes.data, m.size, fast, out.ctypes.data, n)))
+    return out
+
+
+def output_tables(mask):
+    """The 256-word compress / place table of the register SC kernels' output stage (host only, no GPU needed)."""
+    m = np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8)
+    out = np.empty(256, dtype=np.uint32)
+    _check(lib().polar_output_tables(m.ctypes.data, m.size, out.ctypes.data))
     return out
 
 

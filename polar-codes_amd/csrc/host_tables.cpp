@@ -93,3 +93,39 @@ void build_crc_tables(uint64_t crc_poly, int w, int K, std::vector<uint32_t> &E,
     }
     for (int k = 0; k < K; k++) S[k] = R[K - 1 - k];
 }
+
+std::vector<uint32_t> build_compress_tables(const uint8_t *mask, int N)
+{
+    std::vector<uint32_t> tab(256, 0u);
+    if (N < 32 || N > 1024) return tab;
+    std::vector<int> rank(N + 1, 0);  // information positions before position p
+    for (int p = 0; p < N; p++) rank[p + 1] = rank[p] + (mask[p] ? 1 : 0);
+    for (int l = 0; l < 16; l++) {
+        uint32_t per_lane[16] = {0};
+        for (int q = 0; q < 4; q++) {
+            const int p0 = 16 * (l + 16 * q);
+            uint32_t m = 0;
+            if (p0 < N)
+                for (int s = 0; s < 16; s++) m |= (uint32_t)(mask[p0 + s] ? 1 : 0) << s;
+            // compress masks of the 16-bit mask m (the move of step i shifts by 2^i)
+            uint32_t mv[4], mk = (~m << 1) & 0xFFFFu, mm = m;
+            for (int i = 0; i < 4; i++) {
+                uint32_t mp = mk ^ (mk << 1);
+                mp ^= mp << 2;
+                mp ^= mp << 4;
+                mp ^= mp << 8;
+                mp &= 0xFFFFu;
+                mv[i] = mp & mm;
+                mm = ((mm ^ mv[i]) | (mv[i] >> (1 << i))) & 0xFFFFu;
+                mk &= ~mp;
+            }
+            const int w = q >> 1, sh = 16 * (q & 1);
+            per_lane[5 * w] |= m << sh;
+            for (int i = 0; i < 4; i++) per_lane[5 * w + 1 + i] |= mv[i] << sh;
+            const int off = p0 < N ? rank[p0] : 0;
+            per_lane[10 + q] = (uint32_t)(4 * (off >> 5)) | ((uint32_t)(off & 31) << 16);
+        }
+        for (int j = 0; j < 16; j++) tab[(size_t)(16 * (j >> 2) + l) * 4 + (j & 3)] = per_lane[j];
+    }
+    return tab;
+}

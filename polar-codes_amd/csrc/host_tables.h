@@ -1,5 +1,6 @@
 // Host-only declarations: the decoder schedule encoding and the table builders of host_tables.cpp (no HIP needed).
 #pragma once
+// (see build_compress_tables below for the table of the register SC kernels' output stage)
 #include <stdint.h>
 
 #include <vector>
@@ -37,3 +38,12 @@ std::vector<uint32_t> build_schedule(const uint8_t *mask, int N, bool fast, bool
 std::vector<int32_t> critical_set(const uint8_t *mask, int N, int after);
 // CRC remainder maps of a K-bit information word whose last w bits are the CRC of generator crc_poly (leading term included)
 void build_crc_tables(uint64_t crc_poly, int w, int K, std::vector<uint32_t> &E, std::vector<uint32_t> &S);
+
+// Table of the register SC kernels' output stage (N = 32 .. 1024), 256 words.  After the 16 x 16 bit transpose across
+// the lanes of a frame's row, lane l holds the u_hat bits of code positions 16 (l + 16 q) .. + 15 in halfword q of its
+// slice (q = 0 .. 3, two halfwords per 32-bit word).  Per lane and word: the information mask of the two halfwords and
+// the four move masks that compress each halfword's information bits towards its bit 0 (parallel suffix method, 16-bit
+// halves handled independently); per lane and halfword: where the compressed piece goes in the frame's information
+// words, as (byte offset of the word) | (bit offset << 16).  Layout: word (4 g + i) of lane l at [(16 g + l) * 4 + i];
+// per lane words 0 .. 4 = mask, moves of slice word 0, 5 .. 9 = of slice word 1, 10 .. 13 = the four places.
+std::vector<uint32_t> build_compress_tables(const uint8_t *mask, int N);

@@ -91,7 +91,7 @@ template <typename T, int NLOG> struct PbfRegWave {
     uint32_t maskv;
     int lane, grp, sub;
     uint32_t *stage;        // this wavefront's output stage
-    const uint16_t *asl;    // gather table (workgroup)
+    const uint32_t *ctab;   // compress / place table of the output stage (workgroup)
     const uint32_t *crc;    // CRC remainder of every information bit (workgroup)
     T *dl;                  // N decision LLRs of row 0's last ranking run
     double *Mv;             // maxS ranking keys
@@ -129,7 +129,7 @@ template <typename T, int NLOG> struct PbfRegWave {
     // information words and CRC of the rows' last runs; true in the lanes of the rows whose CRC holds
     __device__ __forceinline__ bool test()
     {
-        sc_reg_words<NLOG>(d.root, stage, asl, lane, p.K, p.Kw, true, w_lo, w_hi);
+        sc_reg_words_c<NLOG>(d.root, stage, ctab, lane, rc, w_lo, w_hi);
         uint32_t syn = 0u;
         for (uint32_t v = w_lo; v; v &= v - 1u) syn ^= crc[32 * sub + __ffs((int)v) - 1];
         for (uint32_t v = w_hi; v; v &= v - 1u) syn ^= crc[32 * (sub + 16) + __ffs((int)v) - 1];
@@ -207,16 +207,16 @@ template <typename T, int NLOG> struct PbfRegWave {
 
 template <typename T, int NLOG, int MODE>
 __global__ void __launch_bounds__(64 * PBF_WAVES, sizeof(T) == 8 ? 2 : 4) pbf_reg_kernel(PBFParams<T> p, const uint32_t *__restrict__ maskw,
-                                                                                      const uint16_t *__restrict__ Asl)
+                                                                                      const uint32_t *__restrict__ ctab)
 {
     constexpr int N = 1 << NLOG;
     __shared__ __attribute__((aligned(32))) uint32_t stage_s[PBF_WAVES * SC_STAGE_WORDS];
-    __shared__ uint16_t asl_s[GatherShape<NLOG>::WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t ctab_s[256];
     __shared__ uint32_t misc_s[PBF_WAVES];
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];  // CRC table, then per wavefront: dl, Mv, order
     uint32_t *crc_s = reinterpret_cast<uint32_t *>(dyn);
     const int crc_words = (p.K + 63) & ~63;  // 32 words per lane and word slot, whatever K is
-    for (int k = threadIdx.x; k < GatherShape<NLOG>::WORDS; k += 64 * PBF_WAVES) asl_s[k] = Asl[k];
+    for (int k = threadIdx.x; k < 256; k += 64 * PBF_WAVES) ctab_s[k] = ctab[k];
     for (int k = threadIdx.x; k < 1024; k += 64 * PBF_WAVES) crc_s[k] = k < p.K ? p.crcS[k] : 0u;
     __syncthreads();
     (void)crc_words;
@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(64 * PBF_WAVES, sizeof(T) == 8 ? 2 : 4) pbf_re
     }
     w.maskv = maskw[(w.lane & 31) < (N / 32) ? (w.lane & 31) : 0];
     w.stage = stage_s + wave * SC_STAGE_WORDS;
-    w.asl = asl_s;
+    w.ctab = ctab_s;
     w.crc = crc_s;
     w.misc = misc_s + wave;
     const size_t per_wave = (size_t)N * sizeof(T) + (size_t)p.maxS * 8 + (((size_t)p.maxS * 2 + 15) & ~(size_t)15);
@@ -362,21 +362,21 @@ int launch_pbf_reg_t(polar_code *c, PBFParams<T> &p, int64_t B, const PbfSplit *
     const int64_t resident = (int64_t)ctx->num_cus * occ;
     const int64_t grid = std::min<int64_t>((B + PBF_WAVES - 1) / PBF_WAVES, resident);
     LaunchTimer tm(ctx);
-    hipLaunchKernelGGL(k0, dim3((unsigned)grid), dim3(64 * PBF_WAVES), lds, ctx->stream, p, (const uint32_t *)c->d_maskw, (const uint16_t *)c->d_Asl);
+    hipLaunchKernelGGL(k0, dim3((unsigned)grid), dim3(64 * PBF_WAVES), lds, ctx->stream, p, (const uint32_t *)c->d_maskw, (const uint32_t *)c->d_ctab);
     HIP_TRY(hipGetLastError());
     if (split) {
         p.work = split->ctr;
         p.max_level = 2;
-        hipLaunchKernelGGL(k1, dim3((unsigned)resident), dim3(64 * PBF_WAVES), lds, ctx->stream, p, (const uint32_t *)c->d_maskw, (const uint16_t *)c->d_Asl);
+        hipLaunchKernelGGL(k1, dim3((unsigned)resident), dim3(64 * PBF_WAVES), lds, ctx->stream, p, (const uint32_t *)c->d_maskw, (const uint32_t *)c->d_ctab);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(k2, dim3((unsigned)grid), dim3(64 * PBF_WAVES), lds, ctx->stream, p, (const uint32_t *)c->d_maskw, (const uint16_t *)c->d_Asl);
+        hipLaunchKernelGGL(k2, dim3((unsigned)grid), dim3(64 * PBF_WAVES), lds, ctx->stream, p, (const uint32_t *)c->d_maskw, (const uint32_t *)c->d_ctab);
         HIP_TRY(hipGetLastError());
     }
     const float ms = tm.stop();
     snprintf(c->last.kernel, sizeof(c->last.kernel), "pbf_reg_kernel<%s,%d>/T%d%s", sizeof(T) == 4 ? "float" : "double", NLOG, max_level,
              split ? "+pairs" : "");
     c->last.lanes_per_frame = 64;
-    c->last.lds_bytes_per_block = (int)lds + 4 * PBF_WAVES * SC_STAGE_WORDS + 2 * GatherShape<NLOG>::WORDS;
+    c->last.lds_bytes_per_block = (int)lds + 4 * PBF_WAVES * SC_STAGE_WORDS + 1024;
     c->last.block_threads = 64 * PBF_WAVES;
     c->last.grid_blocks = (int)grid;
     c->last.last_ms = ms;

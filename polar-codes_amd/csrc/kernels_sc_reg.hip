@@ -27,14 +27,14 @@
 
 template <typename T, int NLOG, bool FAST>
 __global__ void __launch_bounds__(64, 4) sc_reg_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, NodeClasses nc,
-                                                    const uint32_t *__restrict__ pid16, const uint16_t *__restrict__ Asl, uint32_t *__restrict__ info_hat, int64_t B,
+                                                    const uint32_t *__restrict__ pid16, const uint32_t *__restrict__ ctab, uint32_t *__restrict__ info_hat, int64_t B,
                                                     int K, int Kw, const uint32_t *__restrict__ truth, int nbits,
                                                     unsigned long long *__restrict__ counters)
 {
     __shared__ __attribute__((aligned(32))) uint32_t stage[SC_STAGE_WORDS];  // per frame: 16 lanes x 64-bit slice of u_hat
     constexpr int N = 1 << NLOG;
-    __shared__ uint16_t asl_s[GatherShape<NLOG>::WORDS];  // the gather table of the output stage
-    for (int k = threadIdx.x; k < GatherShape<NLOG>::WORDS; k += 64) asl_s[k] = Asl[k];
+    __shared__ __attribute__((aligned(16))) uint32_t ctab_s[256];  // the compress / place table of the output stage
+    for (int k = threadIdx.x; k < 256; k += 64) ctab_s[k] = ctab[k];
     wave_sync();
     const int lane = threadIdx.x;
     const int grp = lane >> 4;
@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(64, 4) sc_reg_kernel(const T *__restrict__ llr
         d.root = 0;
         decode_node<NLOG, NLOG, FAST>(d, nc, maskv, pidv, chan_lane, 0u, 0, rc);
 
-        sc_reg_epilogue<NLOG>(d.root, stage, asl_s, info_hat, fc, active, lane, K, Kw, truth, nbits, &acc);
+        sc_reg_epilogue_c<NLOG>(d.root, stage, ctab_s, rc, info_hat, fc, active, lane, K, Kw, truth, nbits, &acc);
     }
     if (truth) err_acc_flush(acc, counters);
 }
@@ -240,7 +240,7 @@ template <typename T, int NLOG, bool FAST> static int launch_reg_t(polar_code *c
     int64_t grid = std::min<int64_t>(need, (int64_t)ctx->num_cus * occ * 8);
     LaunchTimer tm(ctx);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), pad, ctx->stream, (const T *)llr, (const uint32_t *)c->d_maskw, nc,
-                       (const uint32_t *)c->d_pid16, (const uint16_t *)c->d_Asl, info_hat, B, c->K, c->Kw, c->count_truth, c->count_nbits,
+                       (const uint32_t *)c->d_pid16, (const uint32_t *)c->d_ctab, info_hat, B, c->K, c->Kw, c->count_truth, c->count_nbits,
                        (unsigned long long *)c->count_dev);
     HIP_TRY(hipGetLastError());
     float ms = tm.stop();

@@ -462,18 +462,12 @@ __device__ __forceinline__ void sc_reg_words(ps_t root, uint32_t *stage, const u
     }
 }
 
-// truth (packed [B x Kw], or NULL): the transmitted information words; their first nbits bits are compared with the
-// decoded ones and the result goes into acc.  info_hat may then be NULL (nothing is stored).  With truth_regs the
-// transmitted words are in tr_lo / tr_hi (lane sub of the frame's row: words sub and sub + 16).
-template <int NLOG>
-__device__ __forceinline__ void sc_reg_epilogue(ps_t root, uint32_t *stage, const uint16_t *Asl, uint32_t *__restrict__ info_hat,
-                                                int64_t fc, bool active, int lane, int K, int Kw,
-                                                const uint32_t *__restrict__ truth = nullptr, int nbits = 0, ErrAcc *acc = nullptr,
-                                                bool truth_regs = false, uint32_t tr_lo = 0u, uint32_t tr_hi = 0u)
+// Second half of the output stage: store the lane's information words and / or compare them with the transmitted ones.
+__device__ __forceinline__ void sc_reg_finish(uint32_t w_lo, uint32_t w_hi, uint32_t *__restrict__ info_hat, int64_t fc, bool active, int lane,
+                                              int K, int Kw, const uint32_t *__restrict__ truth, int nbits, ErrAcc *acc, bool truth_regs,
+                                              uint32_t tr_lo, uint32_t tr_hi)
 {
     const int sub = lane & 15;
-    uint32_t w_lo, w_hi;
-    sc_reg_words<NLOG>(root, stage, Asl, lane, K, Kw, info_hat || truth || truth_regs, w_lo, w_hi);
     if (info_hat || truth || truth_regs) {
         if (info_hat && active) {
             uint32_t *dst = info_hat + fc * Kw;
@@ -511,6 +505,114 @@ __device__ __forceinline__ void sc_reg_epilogue(ps_t root, uint32_t *stage, cons
             }
         }
     }
+}
+
+// truth (packed [B x Kw], or NULL): the transmitted information words; their first nbits bits are compared with the
+// decoded ones and the result goes into acc.  info_hat may then be NULL (nothing is stored).  With truth_regs the
+// transmitted words are in tr_lo / tr_hi (lane sub of the frame's row: words sub and sub + 16).
+template <int NLOG>
+__device__ __forceinline__ void sc_reg_epilogue(ps_t root, uint32_t *stage, const uint16_t *Asl, uint32_t *__restrict__ info_hat,
+                                                int64_t fc, bool active, int lane, int K, int Kw,
+                                                const uint32_t *__restrict__ truth = nullptr, int nbits = 0, ErrAcc *acc = nullptr,
+                                                bool truth_regs = false, uint32_t tr_lo = 0u, uint32_t tr_hi = 0u)
+{
+    uint32_t w_lo, w_hi;
+    sc_reg_words<NLOG>(root, stage, Asl, lane, K, Kw, info_hat || truth || truth_regs, w_lo, w_hi);
+    sc_reg_finish(w_lo, w_hi, info_hat, fc, active, lane, K, Kw, truth, nbits, acc, truth_regs, tr_lo, tr_hi);
+    wave_sync();
+}
+
+// ---- the output stage without a gather ------------------------------------------------------------------------
+// 16 x 16 bit transpose across the lanes of a row, in every halfword of x at once: bit b of lane s becomes bit s of lane b.
+// Four exchange steps (lane distances 8, 4, 2, 1); a step swaps the bit blocks of that size between partner lanes.
+__device__ __forceinline__ uint32_t row_transpose16(uint32_t x, const RowConst &rc)
+{
+    {   // distance 8: whole bytes, one byte permute
+        const uint32_t t = dpp_mov_u32<0x128>(x);  // row_ror:8
+        const uint32_t sel = (rc.lowmask[0] & 0x05050505u) ^ 0x03070105u;  // lower lanes x.b0 t.b0 x.b2 t.b2, upper t.b1 x.b1 t.b3 x.b3
+        x = __builtin_amdgcn_perm(t, x, sel);
+    }
+    {   // distance 4: the partner's word rotated by a nibble, merged under a lane-dependent mask
+        uint32_t t = dpp_banks_u32<0x104, 0x5>(x);                                          // row_shl:4 into quads 0 and 2
+        t = (uint32_t)__builtin_amdgcn_update_dpp((int)t, (int)x, 0x114, 0xF, 0xA, false);  // row_shr:4 into quads 1 and 3
+        const uint32_t amt = 4u ^ (rc.lowmask[1] & 24u), m = 0xF0F0F0F0u ^ rc.lowmask[1];
+        x = __builtin_amdgcn_bitop3_b32(x, __builtin_amdgcn_alignbit(t, t, amt), m, 0xE4);   // (x & m) | (rot & ~m)
+    }
+    {
+        const uint32_t t = dpp_mov_u32<0x4E>(x);  // quad_perm:[2,3,0,1]
+        const uint32_t amt = 2u ^ (rc.lowmask[2] & 28u), m = 0xCCCCCCCCu ^ rc.lowmask[2];
+        x = __builtin_amdgcn_bitop3_b32(x, __builtin_amdgcn_alignbit(t, t, amt), m, 0xE4);
+    }
+    {
+        const uint32_t t = dpp_mov_u32<0xB1>(x);  // quad_perm:[1,0,3,2]
+        const uint32_t amt = 1u ^ (rc.lowmask[3] & 30u), m = 0xAAAAAAAAu ^ rc.lowmask[3];
+        x = __builtin_amdgcn_bitop3_b32(x, __builtin_amdgcn_alignbit(t, t, amt), m, 0xE4);
+    }
+    return x;
+}
+// the information bits of both halfwords of x moved to the low end of their halfword (c: mask and four move masks)
+__device__ __forceinline__ uint32_t compress_halves(uint32_t x, uint32_t m, uint32_t mv0, uint32_t mv1, uint32_t mv2, uint32_t mv3)
+{
+    x &= m;
+    uint32_t t;
+    t = x & mv0;
+    x = (x ^ t) | (t >> 1);
+    t = x & mv1;
+    x = (x ^ t) | (t >> 2);
+    t = x & mv2;
+    x = (x ^ t) | (t >> 4);
+    t = x & mv3;
+    x = (x ^ t) | (t >> 8);
+    return x;
+}
+// Information words sub and sub + 16 of the lane's frame from the root partial sums, without touching one bit at a time:
+// u_hat on the sliced layout, a 16 x 16 bit transpose across the row (lane l then holds code positions 16 (l + 16 q) ..
+// + 15 in halfword q of its slice), the information bits of every halfword compressed to its low end, and the (at most
+// four) pieces of a lane placed at their bit offset in the frame's words with LDS atomics.  ctab: build_compress_tables'
+// 256 words in LDS; out: 256 words of LDS per wavefront (64 per row).  The caller synchronises the wavefront before out is
+// written again.
+template <int NLOG>
+__device__ __forceinline__ void sc_reg_words_c(ps_t root, uint32_t *out, const uint32_t *ctab, int lane, const RowConst &rc, uint32_t &w_lo,
+                                               uint32_t &w_hi)
+{
+    const int grp = lane >> 4, sub = lane & 15;
+    uint32_t lo = (uint32_t)root, hi = (uint32_t)(root >> 32);
+    slice_transform<NLOG>(lo, hi, sub);
+    uint32_t *row = out + 64 * grp;
+    row[sub] = 0u;
+    row[sub + 16] = 0u;
+    row[sub + 32] = 0u;
+    const uint4 c0 = *reinterpret_cast<const uint4 *>(ctab + 4 * sub);          // mask and moves 0 .. 2 of slice word 0
+    const uint4 c1 = *reinterpret_cast<const uint4 *>(ctab + 64 + 4 * sub);     // move 3 of word 0; mask, moves 0, 1 of word 1
+    const uint4 c2 = *reinterpret_cast<const uint4 *>(ctab + 128 + 4 * sub);    // moves 2, 3 of word 1; places of halfwords 0, 1
+    lo = compress_halves(row_transpose16(lo, rc), c0.x, c0.y, c0.z, c0.w, c1.x);
+    wave_sync();
+    auto place = [&](uint32_t piece, uint32_t e) {
+        const uint64_t v = (uint64_t)piece << (e >> 16);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(row) + (e & 0xFFFFu));
+        atomicOr(dst, (uint32_t)v);
+        atomicOr(dst + 1, (uint32_t)(v >> 32));
+    };
+    place(lo & 0xFFFFu, c2.z);
+    if constexpr (NLOG > 8) place(lo >> 16, c2.w);
+    if constexpr (NLOG > 9) {
+        const uint2 c3 = *reinterpret_cast<const uint2 *>(ctab + 192 + 4 * sub);  // places of halfwords 2, 3
+        hi = compress_halves(row_transpose16(hi, rc), c1.y, c1.z, c1.w, c2.x, c2.y);
+        place(hi & 0xFFFFu, c3.x);
+        place(hi >> 16, c3.y);
+    }
+    wave_sync();
+    w_lo = row[sub];
+    w_hi = row[sub + 16];
+}
+template <int NLOG>
+__device__ __forceinline__ void sc_reg_epilogue_c(ps_t root, uint32_t *out, const uint32_t *ctab, const RowConst &rc, uint32_t *__restrict__ info_hat,
+                                                  int64_t fc, bool active, int lane, int K, int Kw, const uint32_t *__restrict__ truth = nullptr,
+                                                  int nbits = 0, ErrAcc *acc = nullptr)
+{
+    uint32_t w_lo, w_hi;
+    sc_reg_words_c<NLOG>(root, out, ctab, lane, rc, w_lo, w_hi);
+    sc_reg_finish(w_lo, w_hi, info_hat, fc, active, lane, K, Kw, truth, nbits, acc, false, 0u, 0u);
     wave_sync();
 }
 
@@ -544,16 +646,16 @@ struct PolarStaticShape {
 // Workgroups of SC_STATIC_WAVES wavefronts share the gather table; everything else is per wavefront (the wavefronts
 // of a workgroup never wait for each other after the table is loaded).
 extern "C" __global__ void __launch_bounds__(64 * SC_STATIC_WAVES, POLAR_STATIC_WAVES) sc_static_kernel(
-    const float *__restrict__ llr, const uint16_t *__restrict__ Asl, uint32_t *__restrict__ info_hat, long long B, int K, int Kw,
+    const float *__restrict__ llr, const uint32_t *__restrict__ ctab, uint32_t *__restrict__ info_hat, long long B, int K, int Kw,
     const uint32_t *__restrict__ truth, int nbits, unsigned long long *__restrict__ counters)
 {
     constexpr int NLOG = POLAR_STATIC_NLOG;
     constexpr int N = 1 << NLOG;
     constexpr int KEPT = PolarStaticShape::KEPT_WORDS;
     __shared__ __attribute__((aligned(32))) uint32_t stage_s[SC_STATIC_WAVES * SC_STAGE_WORDS];
-    __shared__ uint16_t asl_s[GatherShape<NLOG>::WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t ctab_s[256];
     __shared__ float kept_s[SC_STATIC_WAVES * (KEPT > 0 ? KEPT : 1)];
-    for (int k = threadIdx.x; k < GatherShape<NLOG>::WORDS; k += 64 * SC_STATIC_WAVES) asl_s[k] = Asl[k];
+    for (int k = threadIdx.x; k < 256; k += 64 * SC_STATIC_WAVES) ctab_s[k] = ctab[k];
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: frame offsets stay in scalar registers
     const int lane = threadIdx.x & 63;
@@ -576,7 +678,7 @@ extern "C" __global__ void __launch_bounds__(64 * SC_STATIC_WAVES, POLAR_STATIC_
         const bool active = f < B;
         const long long fc = active ? f : B - 1;
         decode_static<PolarStaticProfile, NLOG, 0, 0>(d, llr + fc * N + sub, rc);
-        sc_reg_epilogue<NLOG>(d.root, stage, asl_s, info_hat, fc, active, lane, K, Kw, truth, nbits, &acc);
+        sc_reg_epilogue_c<NLOG>(d.root, stage, ctab_s, rc, info_hat, fc, active, lane, K, Kw, truth, nbits, &acc);
     }
     if (truth) err_acc_flush(acc, counters);
 }

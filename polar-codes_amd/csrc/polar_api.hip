@@ -127,6 +127,17 @@ extern "C" int polar_ctx_enable_timing(polar_ctx *c, int on)
 
 // ---------------------------------------------------------------------------------------------- schedule
 // (the compiler itself is host-only code: host_tables.cpp)
+extern "C" int polar_output_tables(const uint8_t *mask, int N, uint32_t *out256)
+{
+    if (!mask || !out256 || N < 32 || N > 1024 || (N & (N - 1))) {
+        polar_set_error("polar_output_tables: mask, out256 and a power of two 32 <= N <= 1024 are needed");
+        return POLAR_EINVAL;
+    }
+    const std::vector<uint32_t> t = build_compress_tables(mask, N);
+    memcpy(out256, t.data(), 256 * sizeof(uint32_t));
+    return POLAR_OK;
+}
+
 extern "C" int polar_schedule_build(const uint8_t *mask, int N, int fast, uint32_t *out, int cap)
 {
     ARG_TRY(mask != nullptr, "mask is NULL");
@@ -192,6 +203,7 @@ extern "C" int polar_code_create(polar_ctx *ctx, int N, const uint8_t *mask, pol
         for (int i = 0; i < 16; i++) m16 |= (uint32_t)c->mask[16 * b + i] << i;
         pid16[b] = sc_reg_profile_id(m16);
     }
+    const std::vector<uint32_t> ctab = build_compress_tables(c->mask.data(), N);
     if (A.empty()) A.push_back(0);
     if (Asl.empty()) Asl.push_back(0);
     if (Asl8.empty()) Asl8.push_back(0);
@@ -204,7 +216,7 @@ extern "C" int polar_code_create(polar_ctx *ctx, int N, const uint8_t *mask, pol
     int rc;
     if ((rc = up(&c->d_maskw, maskw)) || (rc = up(&c->d_rank, rank)) || (rc = up(&c->d_A, A)) ||
         (rc = up(&c->d_sched[0], c->sched[0])) || (rc = up(&c->d_sched[1], c->sched[1])) ||
-        (rc = up(&c->d_sched[2], c->sched[2])) || (rc = up(&c->d_sched[3], c->sched[3])) || (rc = up(&c->d_Asl, Asl)) || (rc = up(&c->d_Asl8, Asl8)) ||
+        (rc = up(&c->d_sched[2], c->sched[2])) || (rc = up(&c->d_sched[3], c->sched[3])) || (rc = up(&c->d_Asl, Asl)) || (rc = up(&c->d_Asl8, Asl8)) || (rc = up(&c->d_ctab, ctab)) ||
         (rc = up(&c->d_pid16, pid16))) {
         polar_code_destroy(c);
         return rc;
@@ -218,7 +230,7 @@ extern "C" int polar_code_destroy(polar_code *c)
     if (!c) return POLAR_OK;
     (void)hipSetDevice(c->ctx->device);
     (void)hipStreamSynchronize(c->ctx->stream);
-    uint32_t *ps[] = {c->d_maskw, c->d_rank, c->d_A, c->d_sched[0], c->d_sched[1], c->d_sched[2], c->d_sched[3], c->d_Asl, c->d_Asl8,
+    uint32_t *ps[] = {c->d_maskw, c->d_rank, c->d_A, c->d_sched[0], c->d_sched[1], c->d_sched[2], c->d_sched[3], c->d_Asl, c->d_Asl8, c->d_ctab,
                       c->d_crcE, c->d_crcS, c->d_pid16};
     for (uint32_t *p : ps)
         if (p) (void)hipFree(p);

@@ -69,6 +69,7 @@ struct polar_code {
     uint32_t *d_Asl8 = nullptr;    // same for the 8-lanes-per-path layout: (lane-in-path << 7) | bit
     uint32_t *d_pid16 = nullptr;   // max(64, N/16) words: compiled-profile number of each 16-leaf node (register SC kernels)
     void *big_tables = nullptr;    // tables of the long-code SC kernel, built on first use (kernels_sc_big.hip)
+    uint32_t *d_ctab = nullptr;    // compress / place table of the register SC kernels' output stage (build_compress_tables)
     uint32_t *d_Asl = nullptr;     // gather table of the register SC kernels: [bit i][word w] -> (staged word << 5) | bit
     // CRC (0 = none): generator with leading term, degree, and the two linear maps of the remainder
     uint64_t crc_poly = 0;

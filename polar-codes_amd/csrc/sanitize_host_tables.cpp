@@ -28,6 +28,11 @@ int main()
                     total += ops.size();
                 }
             for (int after : {-1, 0, N / 2, N - 1}) total += critical_set(mask.data(), N, after).size();
+            {
+                const std::vector<uint32_t> ct = build_compress_tables(mask.data(), N);
+                if (ct.size() != 256) return 1;
+                total += ct[0] & 1u;
+            }
             for (int w : {1, 8, 24, 32}) {
                 if (w > K) continue;
                 std::vector<uint32_t> E, S;

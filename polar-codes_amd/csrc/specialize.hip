@@ -120,7 +120,7 @@ int launch_sc_static(polar_code *c, const void *llr, uint32_t *info_hat, int64_t
     const int64_t need = (B + per_block - 1) / per_block;
     const int64_t grid = std::min<int64_t>(need, (int64_t)ctx->num_cus * occ * 8);
     const void *a_llr = llr;
-    const void *a_asl = c->d_Asl;
+    const void *a_asl = c->d_ctab;  // the output stage's compress / place table
     void *a_out = info_hat;
     long long a_B = (long long)B;
     int a_K = c->K, a_Kw = c->Kw, a_nbits = c->count_nbits;
