@@ -377,10 +377,11 @@ def main():
             ctx.sync()
             c3 = c3.cpu().tolist()
             extras["ca_scl8_1024_512_crc24"] = {"frames_per_s": nb / (li["last_ms"] * 1e-3), "info_mbps": nb * 512 / (li["last_ms"] * 1e-3) / 1e6,
-                                                "kernel": li["kernel"], "kernel_ms": li["last_ms"], "frames": nb, "fer": c3[1] / nb}
+                                                "kernel": li["kernel"], "kernel_ms": li["last_ms"], "frames": nb, "fer": c3[1] / nb,
+                                                "roofline": leg_roofline(li["kernel"], li["last_ms"], nb, 1024, 536, paths=8)}
             # progressive bit flipping on the same frames: fast SC on all, CRC test, flip search on the failures
             cca.set_reliability(pcf.GA(1024, 536, 2.0))
-            for T, nb in ((1, 1 << 20), (2, 1 << 15)):  # a failing frame costs ~10^2 SC runs at T = 1, ~10^4 at T = 2
+            for T, nb in ((1, 1 << 20), (2, 1 << 18)):  # a failing frame costs ~10^2 SC runs at T = 1, ~10^4 at T = 2
                 rn = torch.zeros(nb, dtype=torch.int32, device=dev)
                 cca.pbf_decode_dev(lca.data_ptr(), np.float32, T, hca.data_ptr(), nb, runs_ptr=rn.data_ptr())
                 ctx.sync()
@@ -393,7 +394,13 @@ def main():
                 ctx.sync()
                 extras["pbf_T%d_1024_512_crc24" % T] = {"frames_per_s": nb / pdt, "info_mbps": nb * 512 / pdt / 1e6, "frames": nb,
                                                         "fer": c3.cpu().tolist()[1] / nb, "mean_sc_runs": float(rn.float().mean().item()),
-                                                        "max_sc_runs": int(rn.max().item()), "search_kernel_ms": cca.last_launch()["last_ms"]}
+                                                        "max_sc_runs": int(rn.max().item()), "search_kernel_ms": cca.last_launch()["last_ms"],
+                                                        "kernel": cca.last_launch()["kernel"]}
+                # roofline of the search: the lane operations of all its SC runs (the runs the reference would make: sum of the
+                # per-frame counts) over the wall time of the call; HBM bytes: every frame's LLRs once
+                runs_total = int(rn.sum().item())
+                extras["pbf_T%d_1024_512_crc24" % T]["roofline"] = leg_roofline(
+                    cca.last_launch()["kernel"], pdt * 1e3, runs_total, 1024, 536, hbm_bytes_per_frame=(4 * 1024 + 67) * nb / runs_total)
             del ica, hca, lca
         except _native.PolarError as e:
             extras["ca_scl8_1024_512_crc24"] = {"error": str(e)}
