@@ -1001,6 +1001,11 @@ extern "C" int polar_mc_run(polar_code *c, int decoder, int L, int dtype, int fl
     HIP_TRY(hipEventRecord(ctx->dec_done[1], main_stream));
     HIP_TRY(hipStreamWaitEvent(ctx->gen_stream, ctx->dec_done[1], 0));
     int64_t idx = 0;
+    struct Overlap {  // decoders size their grids for a GPU they share with the generator while this loop runs
+        polar_ctx *c;
+        explicit Overlap(polar_ctx *x) : c(x) { c->overlapped = true; }
+        ~Overlap() { c->overlapped = false; }
+    } overlap(ctx);
     for (int64_t f0 = 0; f0 < nframes; f0 += chunk, idx++) {
         const int64_t nb = std::min(chunk, nframes - f0);
         const int b = (int)(idx & 1);

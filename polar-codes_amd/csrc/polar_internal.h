@@ -44,6 +44,7 @@ struct polar_ctx {
     hipStream_t stream = nullptr;
     int num_cus = 0;
     int timing = 0;
+    bool overlapped = false;  // a second stream of this context has kernels in flight (the staged Monte-Carlo loop)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // Monte-Carlo pipeline: frames of chunk i+1 are generated on gen_stream while chunk i is decoded
     hipStream_t gen_stream = nullptr;

@@ -118,7 +118,12 @@ int launch_sc_static(polar_code *c, const void *llr, uint32_t *info_hat, int64_t
     if (occ < 1) occ = 1;
     const int64_t per_block = 4 * WAVES;
     const int64_t need = (B + per_block - 1) / per_block;
-    const int64_t grid = std::min<int64_t>(need, (int64_t)ctx->num_cus * occ * 8);
+    // workgroups per resident slot: measured 8.94 / 8.27 / 8.14 / 7.98 ms per 10^7 frames with 1 / 4 / 8 / 32 (more only adds
+    // dispatch time); next to the frame generator of the staged Monte-Carlo loop the long queue starves the other stream
+    // (241 against 407 M frames/s for the loop), so 8 there
+    int rounds = ctx->overlapped ? 8 : 32;
+    if (const char *e = polar_switch("POLAR_STATIC_ROUNDS")) rounds = std::max(1, atoi(e));
+    const int64_t grid = std::min<int64_t>(need, (int64_t)ctx->num_cus * occ * rounds);
     const void *a_llr = llr;
     const void *a_asl = c->d_ctab;  // the output stage's compress / place table
     void *a_out = info_hat;
@@ -151,7 +156,7 @@ int launch_sc_static_mc(polar_code *c, int64_t B, double N0, uint64_t seed, uint
     if (occ < 1) occ = 1;
     const int64_t per_block = 4 * WAVES;
     const int64_t need = (B + per_block - 1) / per_block;
-    const int64_t grid = std::min<int64_t>(need, (int64_t)ctx->num_cus * occ * 8);
+    const int64_t grid = std::min<int64_t>(need, (int64_t)ctx->num_cus * occ * 32);
     const void *a_asl = c->d_Asl;
     long long a_B = (long long)B;
     int a_K = c->K, a_Kw = c->Kw;
