@@ -745,7 +745,9 @@ static int launch_scl_reg_t(polar_code *c, const void *llr, uint32_t *info_hat, 
     int occ = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, pad));
     if (occ < 1) occ = 1;
-    int64_t grid = std::min<int64_t>(B, (int64_t)ctx->num_cus * occ * 8);
+    int rounds = 8;  // workgroups per resident slot
+    if (const char *e = polar_switch("POLAR_SCL_ROUNDS")) rounds = std::max(1, atoi(e));
+    int64_t grid = std::min<int64_t>(B, (int64_t)ctx->num_cus * occ * rounds);
     // one slab per workgroup for the level that lives in global memory (N = 1024: 16 KB each)
     int rc;
     if ((rc = ctx->scl_slab.reserve(std::max<size_t>(4, (size_t)grid * SclStore<NLOG>::GLOBAL_VALUES * sizeof(float))))) return rc;
