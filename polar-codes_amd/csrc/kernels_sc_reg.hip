@@ -237,7 +237,9 @@ template <typename T, int NLOG, bool FAST> static int launch_reg_t(polar_code *c
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, pad));
     if (occ < 1) occ = 1;
     int64_t need = (B + 3) / 4;
-    int64_t grid = std::min<int64_t>(need, (int64_t)ctx->num_cus * occ * 8);
+    int rounds = 16;  // workgroups per resident slot: 573 / 592 / 605 / 607 M frames/s at (1024,512) with 4 / 8 / 16 / 32
+    if (const char *e = polar_switch("POLAR_SC_ROUNDS")) rounds = std::max(1, atoi(e));
+    int64_t grid = std::min<int64_t>(need, (int64_t)ctx->num_cus * occ * rounds);
     LaunchTimer tm(ctx);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), pad, ctx->stream, (const T *)llr, (const uint32_t *)c->d_maskw, nc,
                        (const uint32_t *)c->d_pid16, (const uint32_t *)c->d_ctab, info_hat, B, c->K, c->Kw, c->count_truth, c->count_nbits,
