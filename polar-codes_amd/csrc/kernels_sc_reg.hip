@@ -237,7 +237,9 @@ template <typename T, int NLOG, bool FAST> static int launch_reg_t(polar_code *c
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, pad));
     if (occ < 1) occ = 1;
     int64_t need = (B + 3) / 4;
-    int rounds = 16;  // workgroups per resident slot: 573 / 592 / 605 / 607 M frames/s at (1024,512) with 4 / 8 / 16 / 32
+    // workgroups per resident slot: 573 / 592 / 605 / 607 M frames/s at (1024,512) with 4 / 8 / 16 / 32; 8 while the staged
+    // Monte-Carlo loop's generator shares the GPU (a long queue of decoder workgroups starves the other stream)
+    int rounds = ctx->overlapped ? 8 : 16;
     if (const char *e = polar_switch("POLAR_SC_ROUNDS")) rounds = std::max(1, atoi(e));
     int64_t grid = std::min<int64_t>(need, (int64_t)ctx->num_cus * occ * rounds);
     LaunchTimer tm(ctx);
