@@ -65,6 +65,8 @@ __device__ __forceinline__ float branch_metric_fast(float v, uint32_t u)
     return e >= 1024.0f ? -INFINITY : r;
 }
 
+constexpr int SCL_SLAB_SLOTS = 8192;  // slabs for the level in global memory: at least twice the resident workgroups
+
 // Small per-path state that moves between lane groups at a fork.
 struct PathState {
     float pm;
@@ -606,7 +608,37 @@ __global__ void __launch_bounds__(64, 4) scl_reg_kernel(const float *__restrict_
     SclReg<NLOG, LMAX> d;
     d.my_lane = lc.lane;
     d.lv_lds = lvl_s;
-    d.lv_glb = slab + (size_t)blockIdx.x * SclStore<NLOG>::GLOBAL_VALUES;
+    // The level in global memory (N = 1024) lives in one of SCL_SLAB_SLOTS slabs, claimed here and given back at the end:
+    // the slabs in use are as many as there are resident workgroups, however long the grid is.  slab[0 .. 256) is the
+    // bitmap of claimed slabs (cleared before the launch); there are at least twice as many slabs as resident workgroups,
+    // so the search below always ends.
+    uint32_t slab_word = 0, slab_bit = 0;
+    if constexpr (SclStore<NLOG>::GLOBAL_VALUES > 0) {
+        uint32_t *bm = reinterpret_cast<uint32_t *>(slab);
+        if (lc.lane == 0) {
+            uint32_t w = (blockIdx.x * 5u) & (SCL_SLAB_SLOTS / 32 - 1);
+            for (;;) {
+                const uint32_t cur = __hip_atomic_load(bm + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur != 0xFFFFFFFFu) {
+                    const uint32_t b = (uint32_t)__ffs((int)~cur) - 1u;
+                    if (!(atomicOr(bm + w, 1u << b) & (1u << b))) {
+                        xchg[0] = w;
+                        xchg[1] = b;
+                        break;
+                    }
+                } else {
+                    w = (w + 1u) & (SCL_SLAB_SLOTS / 32 - 1);
+                }
+            }
+        }
+        wave_sync();
+        slab_word = (uint32_t)__builtin_amdgcn_readfirstlane((int)xchg[0]);
+        slab_bit = (uint32_t)__builtin_amdgcn_readfirstlane((int)xchg[1]);
+        wave_sync();
+        d.lv_glb = slab + SCL_SLAB_SLOTS / 32 + (size_t)(slab_word * 32u + slab_bit) * SclStore<NLOG>::GLOBAL_VALUES;
+    } else {
+        d.lv_glb = slab;
+    }
 
     for (int64_t f = blockIdx.x; f < B; f += gridDim.x) {
         const float *chan_lane = llr + f * N + lc.e;
@@ -709,6 +741,12 @@ __global__ void __launch_bounds__(64, 4) scl_reg_kernel(const float *__restrict_
             for (int i = 0; i < 24; i++) atomicAdd(&g_scl_prof[i], prof_acc[i]);
 #endif
     }
+    if constexpr (SclStore<NLOG>::GLOBAL_VALUES > 0) {
+        // every store to the slab has landed before the next owner can claim it
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_wave_barrier();
+        if (lc.lane == 0) atomicAnd(reinterpret_cast<uint32_t *>(slab) + slab_word, ~(1u << slab_bit));
+    }
 }
 
 #ifdef POLAR_SCL_PROFILE
@@ -745,12 +783,18 @@ static int launch_scl_reg_t(polar_code *c, const void *llr, uint32_t *info_hat, 
     int occ = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, pad));
     if (occ < 1) occ = 1;
-    int rounds = 8;  // workgroups per resident slot
+    int rounds = 32;  // workgroups per resident slot: 14.9 / 16.2 / 16.8 / 17.25 M frames/s at (1024,512), L = 8, with 1 / 4 / 8 / 32
     if (const char *e = polar_switch("POLAR_SCL_ROUNDS")) rounds = std::max(1, atoi(e));
     int64_t grid = std::min<int64_t>(B, (int64_t)ctx->num_cus * occ * rounds);
-    // one slab per workgroup for the level that lives in global memory (N = 1024: 16 KB each)
+    // the slabs of the level that lives in global memory (N = 1024: 16 KB each) behind the bitmap of claimed ones
     int rc;
-    if ((rc = ctx->scl_slab.reserve(std::max<size_t>(4, (size_t)grid * SclStore<NLOG>::GLOBAL_VALUES * sizeof(float))))) return rc;
+    if (SclStore<NLOG>::GLOBAL_VALUES > 0 && (int64_t)ctx->num_cus * occ * 2 > SCL_SLAB_SLOTS) {
+        polar_set_error("register list decoder: %d resident workgroups need more than %d slabs", ctx->num_cus * occ, SCL_SLAB_SLOTS);
+        return POLAR_EUNSUPPORTED;
+    }
+    const size_t slab_bytes = SclStore<NLOG>::GLOBAL_VALUES > 0 ? (SCL_SLAB_SLOTS / 32 + (size_t)SCL_SLAB_SLOTS * SclStore<NLOG>::GLOBAL_VALUES) * sizeof(float) : 4;
+    if ((rc = ctx->scl_slab.reserve(slab_bytes))) return rc;
+    if (SclStore<NLOG>::GLOBAL_VALUES > 0) HIP_TRY(hipMemsetAsync(ctx->scl_slab.p, 0, SCL_SLAB_SLOTS / 8, ctx->stream));
     LaunchTimer tm(ctx);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), pad, ctx->stream, (const float *)llr, (const uint32_t *)c->d_maskw,
                        (const uint16_t *)c->d_Asl8, crc ? (const uint32_t *)c->d_crcS : nullptr, truth, info_hat, B, c->K, c->Kw,
