@@ -215,11 +215,9 @@ __global__ void __launch_bounds__(64 * PBF_WAVES, sizeof(T) == 8 ? 2 : 4) pbf_re
     __shared__ uint32_t misc_s[PBF_WAVES];
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];  // CRC table, then per wavefront: dl, Mv, order
     uint32_t *crc_s = reinterpret_cast<uint32_t *>(dyn);
-    const int crc_words = (p.K + 63) & ~63;  // 32 words per lane and word slot, whatever K is
     for (int k = threadIdx.x; k < 256; k += 64 * PBF_WAVES) ctab_s[k] = ctab[k];
-    for (int k = threadIdx.x; k < 1024; k += 64 * PBF_WAVES) crc_s[k] = k < p.K ? p.crcS[k] : 0u;
+    for (int k = threadIdx.x; k < 1024; k += 64 * PBF_WAVES) crc_s[k] = k < p.K ? p.crcS[k] : 0u;  // 32 entries per lane and word slot
     __syncthreads();
-    (void)crc_words;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     PbfRegWave<T, NLOG> w(p);
     w.lane = threadIdx.x & 63;
