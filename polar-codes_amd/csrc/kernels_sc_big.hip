@@ -404,10 +404,10 @@ template <int LEV, int NLOG> __device__ __forceinline__ void big_node(BigCtx<NLO
 }
 
 #ifndef POLAR_BIG_MINWAVES
-#define POLAR_BIG_MINWAVES 2  // wavefronts per SIMD the register allocation aims for
+#define POLAR_BIG_MINWAVES 2  // wavefronts per SIMD the register allocation aims for (N = 2048 keeps nothing of level 11 in registers: 3, 192 against 163 M frames/s)
 #endif
 template <int NLOG>
-__global__ void __launch_bounds__(64, POLAR_BIG_MINWAVES) sc_big_kernel(const float *__restrict__ llr, BigTables t, float *__restrict__ slabs,
+__global__ void __launch_bounds__(64, NLOG == 11 ? 3 : POLAR_BIG_MINWAVES) sc_big_kernel(const float *__restrict__ llr, BigTables t, float *__restrict__ slabs,
                                                     uint32_t *__restrict__ info_hat, int64_t B, int K, int Kw)
 {
     typedef BigLayout<NLOG> Lay;
