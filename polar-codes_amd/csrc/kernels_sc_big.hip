@@ -3,7 +3,7 @@
 // The same mapping as sc_reg_kernel -- sixteen lanes per frame, four frames per wavefront, element k of every
 // tree level in lane k mod 16.  Where a level lives depends on its width:
 //   * levels of 4096 elements and more (below the channel) in a slab of global memory per frame (level l at offset
-//     2^l - 1024) with their partial sums beside them as per-lane bit slices.  A lane only ever touches the elements
+//     2^l - 4096) with their partial sums beside them as per-lane bit slices.  A lane only ever touches the elements
 //     of its own residue, so the slab needs no synchronisation at all, and the order of a level inside the slab is
 //     free: element 16 j + s sits at index 64 (j / 4) + 4 s + j % 4, four elements of a lane side by side, so that a
 //     step moves 16 bytes per lane and 256 contiguous bytes per frame and instruction;
@@ -41,12 +41,13 @@ struct BigTables {
     int KwPad;
 };
 
-// Slab of one frame, in 32-bit words: LLR levels 10 .. n-1, then the partial-sum planes.
-// Partial sums of level l (10 <= l <= n): 2^(l-9) words per lane, word w of lane s at [w * 16 + s]; two planes.
+// Slab of one frame, in 32-bit words: the LLR levels that are stored (12 .. n-1; none for N = 2048), then the partial-sum
+// planes.  Partial sums of level l (10 <= l <= n): 2^(l-9) words per lane, word w of lane s at [w * 16 + s]; two planes.
 template <int NLOG> struct BigLayout {
     static constexpr int N = 1 << NLOG;
-    static constexpr int LLR_WORDS = N - 1024;
-    static __device__ __host__ constexpr int llr_off(int l) { return (1 << l) - 1024; }
+    static constexpr int LLR_BASE = NLOG > 11 ? 4096 : N;  // levels below 12 live on chip
+    static constexpr int LLR_WORDS = N - LLR_BASE;
+    static __device__ __host__ constexpr int llr_off(int l) { return (1 << l) - LLR_BASE; }
     static __device__ __host__ constexpr int ps_words(int l) { return 16 << (l - 9); }           // one plane of level l
     static __device__ __host__ constexpr int ps_off(int l, int plane)                            // levels 10 .. n
     {
@@ -145,9 +146,12 @@ __device__ __forceinline__ glb_float *opaque_ptr(float *p)
     return g;
 }
 
-__device__ __forceinline__ float4 f_fast4(const float4 &a, const float4 &b)
+// f of four pairs.  Measured per length with both forms of f (M frames/s, f_med / f_fast): 8192: 27.3 / 22.7, 16384: 10.1 / 8.8,
+// 32768: 3.68 / 3.36, 65536: 1.49 / 1.38, but 4096: 48.4 / 58.1 (there the only such step reads the channel).
+template <int NLOG> __device__ __forceinline__ float4 f_fast4(const float4 &a, const float4 &b)
 {
-    return make_float4(f_med(a.x, b.x), f_med(a.y, b.y), f_med(a.z, b.z), f_med(a.w, b.w));
+    if constexpr (NLOG == 12) return make_float4(f_fast(a.x, b.x), f_fast(a.y, b.y), f_fast(a.z, b.z), f_fast(a.w, b.w));
+    else return make_float4(f_med(a.x, b.x), f_med(a.y, b.y), f_med(a.z, b.z), f_med(a.w, b.w));
 }
 
 // f / g from level LEV (the channel, or a level >= 12 of the slab) to LEV-1: elements sub + 16 j of the lane's residue,
@@ -174,7 +178,7 @@ template <int LEV, int NLOG, bool IS_G> __device__ __forceinline__ float4 big_tr
         return make_float4(g_fast(a.x, b.x, w & 1u), g_fast(a.y, b.y, (w >> 1) & 1u), g_fast(a.z, b.z, (w >> 2) & 1u),
                            g_fast(a.w, b.w, (w >> 3) & 1u));
     }
-    return f_fast4(a, b);
+    return f_fast4<NLOG>(a, b);
 }
 // trip J of level L goes to its home: the slab (L >= 12), the on-chip level 11 (registers for the first half, LDS for
 // the second) or, for N = 2048, the subtree's LLR registers.  For L <= 11 J must be a compile-time constant after unrolling.
@@ -211,7 +215,7 @@ template <int L, int NLOG, int CNT, int TM, int W> __device__ __forceinline__ vo
     if constexpr (CNT >= 1) {
 #pragma unroll
         for (int i = 0; i < CNT; i++) {
-            v[i] = f_fast4(v[i], v[i + CNT]);
+            v[i] = f_fast4<NLOG>(v[i], v[i + CNT]);
             big_put<L, NLOG>(cx, slab, t + i * TM, v[i], sq);
         }
         big_descend<L - 1, NLOG, CNT / 2, TM, W>(cx, slab, v, t, sq);

@@ -6,7 +6,7 @@ import sys, os; sys.path[:0]=['polar-codes_amd','.']
 import numpy as np, torch, _native, functions as pcf
 from channel import Channel
 ctx=_native.default_ctx(0); ctx.enable_timing(True)
-for (N,K,nb) in [(16384,8192,1<<15),(4096,2048,1<<17),(65536,30000,1<<13),(2048,1000,1<<18)]:
+for (N,K,nb) in [(16384,8192,1<<15),(4096,2048,1<<17),(65536,30000,1<<14),(2048,1000,1<<18),(8192,4096,1<<16),(32768,16384,1<<14)]:
     code=_native.Code(ctx,pcf.degaBuild(N,K,2.0)); n0=Channel('BPSK',2.0,'SNRb',K/N).noisePower
     llr=torch.empty((nb,N),dtype=torch.float32,device='cuda'); hat=torch.empty((nb,code.Kw),dtype=torch.int32,device='cuda')
     code.gen_frames_dev(None,llr.data_ptr(),np.float32,n0,1,0,nb)
