@@ -244,6 +244,7 @@ template <int LEV, int NLOG, bool IS_G, int D> __device__ __forceinline__ void b
 #pragma unroll
         for (int i = 0; i < W; i++) big_put<LEV - 1, NLOG>(cx, slab, t + i * TM, v[i], sq);
         big_descend<LEV - 2, NLOG, W / 2, TM, W>(cx, slab, v, t, sq);
+        if constexpr (D >= 3) __builtin_amdgcn_sched_barrier(0);
     };
     if constexpr (M <= 11) {
 #pragma unroll
