@@ -244,7 +244,11 @@ template <int LEV, int NLOG, bool IS_G, int D> __device__ __forceinline__ void b
 #pragma unroll
         for (int i = 0; i < W; i++) big_put<LEV - 1, NLOG>(cx, slab, t + i * TM, v[i], sq);
         big_descend<LEV - 2, NLOG, W / 2, TM, W>(cx, slab, v, t, sq);
-        if constexpr (D >= 3) __builtin_amdgcn_sched_barrier(0);
+        // Trips are kept apart where a trip is long (two or three levels at once, or the 4-byte loads of the channel going
+        // straight to the on-chip level): letting the scheduler interleave them costs more registers than there are.
+        // Measured, M frames/s without / with: N = 16384: 10.0 / 10.8, 8192: 27.4 / 30.7, 4096: 57 / 64; a barrier after
+        // the other single steps loses (2048: 189 -> 163).
+        if constexpr (D >= 2 || (LEV == NLOG && LEV == 12)) __builtin_amdgcn_sched_barrier(0);
     };
     if constexpr (M <= 11) {
 #pragma unroll
