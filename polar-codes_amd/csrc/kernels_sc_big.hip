@@ -422,7 +422,9 @@ __global__ void __launch_bounds__(64, NLOG == 11 ? 3 : POLAR_BIG_MINWAVES) sc_bi
     typedef BigLayout<NLOG> Lay;
     constexpr int N = 1 << NLOG;
     const int lane = threadIdx.x, grp = lane >> 4, sub = lane & 15;
-    __shared__ float hi_lds[BigCtx<NLOG>::CHIP ? 64 * 64 : 1];  // second half of the level-11 node, one column per lane
+    // second half of the level-11 node, one column per lane; the output stage keeps the four frames' u_hat there
+    constexpr int UHAT_LDS_WORDS = BigCtx<NLOG>::CHIP ? 64 * 64 : 256;
+    __shared__ float hi_lds[UHAT_LDS_WORDS];
     BigCtx<NLOG> cx;
     cx.t = t;
     cx.sub = sub;
@@ -446,35 +448,73 @@ __global__ void __launch_bounds__(64, NLOG == 11 ? 3 : POLAR_BIG_MINWAVES) sc_bi
         // u_hat = x_hat F^{(x)n} on the sliced root (bit j of lane s = element 16 j + s; 2^(NLOG-9) words per lane)
         uint32_t *x = reinterpret_cast<uint32_t *>(cx.slab) + Lay::ps_off(NLOG, 0);
         constexpr int W = 1 << (NLOG - 9);
-        // stages 4 .. 8 pair bits inside a word, stages 9 .. pair words of the lane
-        for (int w = 0; w < W; w++) {
-            uint32_t v = x[w * 16 + sub];
-            v ^= (v >> 1) & 0x55555555u;
-            v ^= (v >> 2) & 0x33333333u;
-            v ^= (v >> 4) & 0x0F0F0F0Fu;
-            v ^= (v >> 8) & 0x00FF00FFu;
-            v ^= (v >> 16) & 0x0000FFFFu;
-            x[w * 16 + sub] = v;
-        }
-        for (int d = 1; d < W; d <<= 1)
-            for (int w = 0; w < W; w++)
-                if (!(w & d)) x[w * 16 + sub] ^= x[(w + d) * 16 + sub];
-        // stages 0 .. 3 pair lanes of the row
-        {
+        constexpr bool IN_LDS = 4 * 16 * W <= UHAT_LDS_WORDS;  // the four frames' u_hat fit the LDS area: transform in registers
+        const uint32_t *xg;                                     // where the gather below reads word i of this frame's u_hat: xg[i]
+        if constexpr (IN_LDS) {
+            uint32_t xw[W];
+#pragma unroll
+            for (int w = 0; w < W; w++) xw[w] = x[w * 16 + sub];
+            // stages 4 .. 8 pair bits inside a word, stages 9 .. pair words of the lane, stages 0 .. 3 lanes of the row
             const uint32_t odd1 = (sub & 1) ? 0xFFFFFFFFu : 0u, odd2 = (sub & 2) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
             for (int w = 0; w < W; w++) {
-                uint32_t v = x[w * 16 + sub];
+                uint32_t v = xw[w];
+                v ^= (v >> 1) & 0x55555555u;
+                v ^= (v >> 2) & 0x33333333u;
+                v ^= (v >> 4) & 0x0F0F0F0Fu;
+                v ^= (v >> 8) & 0x00FF00FFu;
+                v ^= (v >> 16) & 0x0000FFFFu;
+                xw[w] = v;
+            }
+#pragma unroll
+            for (int d = 1; d < W; d <<= 1)
+#pragma unroll
+                for (int w = 0; w < W; w++)
+                    if (!(w & d)) xw[w] ^= xw[w + d];
+            uint32_t *xl = reinterpret_cast<uint32_t *>(hi_lds) + grp * 16 * W;
+#pragma unroll
+            for (int w = 0; w < W; w++) {
+                uint32_t v = xw[w];
                 v ^= dpp_mov_u32<0xB1>(v & odd1);
                 v ^= dpp_mov_u32<0x4E>(v & odd2);
                 v ^= dpp_banks_u32<0x104, 0x5>(v);
                 v ^= dpp_banks_u32<0x108, 0x3>(v);
+                xl[w * 16 + sub] = v;
+            }
+            wave_sync();
+            xg = xl;
+        } else {
+            // stages 4 .. 8 pair bits inside a word, stages 9 .. pair words of the lane
+            for (int w = 0; w < W; w++) {
+                uint32_t v = x[w * 16 + sub];
+                v ^= (v >> 1) & 0x55555555u;
+                v ^= (v >> 2) & 0x33333333u;
+                v ^= (v >> 4) & 0x0F0F0F0Fu;
+                v ^= (v >> 8) & 0x00FF00FFu;
+                v ^= (v >> 16) & 0x0000FFFFu;
                 x[w * 16 + sub] = v;
             }
+            for (int d = 1; d < W; d <<= 1)
+                for (int w = 0; w < W; w++)
+                    if (!(w & d)) x[w * 16 + sub] ^= x[(w + d) * 16 + sub];
+            // stages 0 .. 3 pair lanes of the row
+            {
+                const uint32_t odd1 = (sub & 1) ? 0xFFFFFFFFu : 0u, odd2 = (sub & 2) ? 0xFFFFFFFFu : 0u;
+                for (int w = 0; w < W; w++) {
+                    uint32_t v = x[w * 16 + sub];
+                    v ^= dpp_mov_u32<0xB1>(v & odd1);
+                    v ^= dpp_mov_u32<0x4E>(v & odd2);
+                    v ^= dpp_banks_u32<0x104, 0x5>(v);
+                    v ^= dpp_banks_u32<0x108, 0x3>(v);
+                    x[w * 16 + sub] = v;
+                }
+            }
+            // the other lanes of the row read these words next
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            xg = x;
         }
-        // the other lanes of the row read these words next
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         // lane s assembles output words s, s + 16, ...
         for (int w = sub; w < Kw; w += 16) {
             uint32_t acc = 0;
@@ -482,7 +522,7 @@ __global__ void __launch_bounds__(64, NLOG == 11 ? 3 : POLAR_BIG_MINWAVES) sc_bi
 #pragma unroll 8
             for (int i = 0; i < 32; i++) {
                 const uint32_t e = g[(size_t)i * t.KwPad];
-                acc = __builtin_amdgcn_alignbit(x[e >> 5] >> (e & 31u), acc, 1);
+                acc = __builtin_amdgcn_alignbit(xg[e >> 5] >> (e & 31u), acc, 1);
             }
             const int valid = K - 32 * w;
             if (valid < 32) acc &= (1u << valid) - 1u;
@@ -490,6 +530,7 @@ __global__ void __launch_bounds__(64, NLOG == 11 ? 3 : POLAR_BIG_MINWAVES) sc_bi
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
+        wave_sync();  // the LDS area goes back to the decoder
     }
 }
 
