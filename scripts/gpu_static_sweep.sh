@@ -1,7 +1,7 @@
 # specialised SC decoder: channel pairs kept in registers x pairs kept in LDS x target occupancy (workgroups of 4 waves
 # per CU = waves per SIMD)
 export POLAR_EXPERIMENT=1  # the library reads its kernel switches only with this set
-for CFG in "16 16 4" "16 0 4" "16 8 4" "8 16 4" "24 8 4" "0 16 4" "0 16 5" "8 16 5" "12 16 4"; do
+for CFG in "16 16 4" "12 16 4" "12 20 4" "8 16 4" "8 24 4" "20 12 4" "4 16 5" "8 12 5" "16 16 4"; do
   set -- $CFG
   POLAR_STATIC_KEEP=$1 POLAR_STATIC_KEEP_LDS=$2 POLAR_STATIC_WAVES=$3 timeout -k 10 120 python3 bench.py --no-cpu --no-extras > gpurun_out/ss.log 2>&1 || { tail -3 gpurun_out/ss.log; exit 1; }
   python3 -c "
