@@ -1,5 +1,5 @@
-// Register-resident list decoder, up to L = 8 paths (L = 2 and 4 leave positions empty), N = 64 .. 1024, fp32: one wavefront per frame, eight lanes
-// per path.
+// Register-resident list decoder, up to L = 8 paths (L = 2 and 4 leave positions empty), N = 64 .. 1024, fp32 or fp64: one
+// wavefront per frame, eight lanes per path.
 //
 // Lane 8p + q belongs to list position p.  Inside a path, element k of every tree level lives in the lane
 // whose element index e(q) equals k mod 8 (e = q for q < 4, 11 - q otherwise, so that the three bottom
@@ -17,8 +17,9 @@
 // Path metric and ordering follow the reference's sclDecoder / polarSCLFork: PM += 1 - log2(1 + 2^(-+Li));
 // below saturation list = originals ++ copies; at saturation the 16 candidates, ordered copies(u=1) ++
 // originals(u=0), are ranked by (metric descending, candidate position ascending) and rank r < 8 becomes
-// position r.  The metric uses the overflow-free fp32 form with hardware exp2/log2: this kernel is the
-// throughput mode (statistical parity); fp64 parity runs on the LDS-staged kernel.
+// position r.  In fp32 (the throughput mode, statistical parity) the metric uses the overflow-free form with hardware
+// exp2/log2; in fp64 (the parity mode) it is evaluated as the reference writes it, operation by operation, as in the
+// LDS-staged kernel: the two fp64 kernels give the same bits and the same metrics.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -32,6 +33,12 @@ __device__ __forceinline__ float bperm_f(float v, int src_lane)
 {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
 }
+__device__ __forceinline__ double bperm_f(double v, int src_lane)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ uint32_t bperm_u(uint32_t v, int src_lane)
 {
     return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
@@ -42,7 +49,7 @@ __device__ __forceinline__ uint64_t bperm_u64(uint64_t v, int src_lane)
 }
 
 // partner exchange inside an 8-lane path for a period-P replicated vector
-template <int P> __device__ __forceinline__ float partner8(float v)
+template <int P, typename T> __device__ __forceinline__ T partner8(T v)
 {
     if constexpr (P == 8) return dpp_mov<0x141>(v);       // row_half_mirror: lane i <-> 7 - i of each 8
     else if constexpr (P == 4) return dpp_mov<0x4E>(v);   // quad_perm:[2,3,0,1]
@@ -55,6 +62,55 @@ template <int P> __device__ __forceinline__ uint32_t partner8_u(uint32_t v)
     else return dpp_mov_u32<0xB1>(v);
 }
 
+// value of lane `src` (wave-uniform)
+__device__ __forceinline__ float lane_value(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+__device__ __forceinline__ double lane_value(double v, int src)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+
+// integer with the order of the metric (no NaN and no -0 occurs among metrics)
+__device__ __forceinline__ uint32_t order_key(float v)
+{
+    const uint32_t x = __float_as_uint(v);
+    return x ^ ((uint32_t)((int32_t)x >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ uint64_t order_key(double v)
+{
+    const uint64_t x = (uint64_t)__double_as_longlong(v);
+    return x ^ ((uint64_t)((int64_t)x >> 63) | 0x8000000000000000ull);
+}
+__device__ __forceinline__ uint32_t bperm_key(uint32_t k, int byte_addr) { return (uint32_t)__builtin_amdgcn_ds_bpermute(byte_addr, (int)k); }
+__device__ __forceinline__ uint64_t bperm_key(uint64_t k, int byte_addr)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(byte_addr, (int)(uint32_t)k);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(byte_addr, (int)(uint32_t)(k >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// a real number in the word-major exchange records of the pruning step (word w of a record at rec[64 * w])
+__device__ __forceinline__ void rec_put(uint32_t *rec, int &w, float v) { rec[64 * w++] = __float_as_uint(v); }
+__device__ __forceinline__ void rec_put(uint32_t *rec, int &w, double v)
+{
+    rec[64 * w++] = (uint32_t)__double2loint(v);
+    rec[64 * w++] = (uint32_t)__double2hiint(v);
+}
+__device__ __forceinline__ void rec_get(const uint32_t *rec, int &w, float &v) { v = __uint_as_float(rec[64 * w++]); }
+__device__ __forceinline__ void rec_get(const uint32_t *rec, int &w, double &v)
+{
+    const uint32_t lo = rec[64 * w++];
+    const uint32_t hi = rec[64 * w++];
+    v = __hiloint2double((int)hi, (int)lo);
+}
+
+// fp64 branch metric: the reference's expression, operation by operation (cn/polarCode.py:982-988 and :2066-2067, as
+// scl_decode_kernel<double, L> evaluates it)
+__device__ __forceinline__ double branch_metric_fast(double v, uint32_t u)
+{
+    const double Li = v / 0.693147180559945309417232121458;
+    const double e = u ? Li : -Li;
+    return 1.0 - log2(1.0 + exp2(e));
+}
 // fp32 branch metric of deciding u at decision LLR v (overflow-free; -inf only where the reference overflows)
 __device__ __forceinline__ float branch_metric_fast(float v, uint32_t u)
 {
@@ -68,11 +124,11 @@ __device__ __forceinline__ float branch_metric_fast(float v, uint32_t u)
 constexpr int SCL_SLAB_SLOTS = 8192;  // slabs for the level in global memory: at least twice the resident workgroups
 
 // Small per-path state that moves between lane groups at a fork.
-struct PathState {
-    float pm;
+template <typename T> struct PathState {
+    T pm;
     uint32_t ownL;   // 3 bits per level l (index l - 3): position whose registers hold my level-l LLRs; bits 24..26: see XB
     uint32_t ownP;   // same for the left-child partial sums of level l
-    float v[3];      // my element of the LLRs of the enclosing 8-, 4- and 2-leaf nodes, until their g has run
+    T v[3];          // my element of the LLRs of the enclosing 8-, 4- and 2-leaf nodes, until their g has run
     // bit XB + I of ownL: partial-sum bit of the finished left child of the enclosing node I (one word less to move at a fork)
 };
 
@@ -119,20 +175,32 @@ struct LaneConst {
 // kernel is bound by the latency of one wavefront's instruction stream (its rate is proportional to the wavefronts
 // per CU).  The two widest levels therefore live elsewhere: level 9 (64 values per lane, touched by four steps per
 // frame) in a per-workgroup slab of global memory, level 8 (32 values) in LDS, each lane-major ([j][lane]) so that a
-// step is 64 coalesced lanes; the registers keep levels 3 .. 7 and a third wavefront fits.
-template <int NLOG> struct SclStore {
-    static constexpr int GLOBAL_LEVEL = NLOG == 10 ? 9 : 99;
-    static constexpr int LDS_LEVEL = NLOG == 10 ? 8 : 99;
-    static constexpr int REG_VALUES = NLOG == 10 ? 32 : (1 << (NLOG - 3));
-    static constexpr int LDS_VALUES = NLOG == 10 ? 32 * 64 : 1;       // floats per wavefront
-    static constexpr int GLOBAL_VALUES = NLOG == 10 ? 64 * 64 : 0;    // floats per wavefront
+// step is 64 coalesced lanes; the registers keep levels 3 .. 7 and a third wavefront fits.  fp64 values take two
+// registers each, so that mode splits one level earlier (from N = 512 on): levels 3 .. 6 in registers, level 7 in
+// LDS, levels 8 and 9 in the slab.
+template <int NLOG, typename T> struct SclStore {
+    static constexpr int TOP = NLOG - 1;  // widest stored level
+    static constexpr bool SPLIT = sizeof(T) == 4 ? NLOG == 10 : NLOG >= 9;
+    static constexpr int REG_TOP = !SPLIT ? TOP : (sizeof(T) == 4 ? 7 : 6);
+    static constexpr int LDS_LEVEL = SPLIT ? REG_TOP + 1 : 99;
+    static constexpr int GLOBAL_MIN = SPLIT ? REG_TOP + 2 : 99;   // levels from here up live in the slab
+    static constexpr int REG_VALUES = 1 << (REG_TOP - 2);         // level l at offset 2^(l-3)
+    static constexpr int LDS_VALUES = SPLIT ? (1 << (LDS_LEVEL - 3)) * 64 : 1;  // values per wavefront
+    static constexpr int glb_row(int l)                           // first slab row (64 lanes) of level l
+    {
+        int o = 0;
+        for (int i = GLOBAL_MIN; i < l; i++) o += 1 << (i - 3);
+        return o;
+    }
+    static constexpr int GLOBAL_VALUES = SPLIT ? glb_row(TOP + 1) * 64 : 0;     // values per wavefront
 };
 
-template <int NLOG, int LMAX = 8> struct SclReg {
-    static constexpr int S = SclStore<NLOG>::REG_VALUES;
-    float R[S];           // level l (3 <= l < NLOG) kept in registers: 2^(l-3) values at offset 2^(l-3)
-    float *lv_lds;        // the LDS level of this wavefront (wave-uniform)
-    float *lv_glb;        // the global level of this wavefront (wave-uniform)
+template <int NLOG, int LMAX, typename T> struct SclReg {
+    using St = SclStore<NLOG, T>;
+    static constexpr int S = St::REG_VALUES;
+    T R[S];               // level l (3 <= l <= REG_TOP) kept in registers: 2^(l-3) values at offset 2^(l-3)
+    T *lv_lds;            // the LDS level of this wavefront (wave-uniform)
+    T *lv_glb;            // the slab of this wavefront (wave-uniform)
     int my_lane;
 
     // element j of my level L / of the level-L values that the lanes `src` (owner position * 8 + q) hold / store.
@@ -144,39 +212,45 @@ template <int NLOG, int LMAX = 8> struct SclReg {
         asm volatile("" : "+v"(v));
         return v;
     }
-    template <int L> __device__ __forceinline__ float ld_own(int j, int lq) const
+    // the same for the frame's channel pointer in fp64, whose strided elements reach beyond the offset field of a load
+    static __device__ __forceinline__ const T *opaque(const T *ptr)
     {
-        if constexpr (L == SclStore<NLOG>::GLOBAL_LEVEL) return lv_glb[j * 64 + lq];
-        else if constexpr (L == SclStore<NLOG>::LDS_LEVEL) return lv_lds[j * 64 + lq];
+        if constexpr (sizeof(T) == 8) asm volatile("" : "+v"(ptr));
+        return ptr;
+    }
+    template <int L> __device__ __forceinline__ T ld_own(int j, int lq) const
+    {
+        if constexpr (L >= St::GLOBAL_MIN) return lv_glb[(St::glb_row(L) + j) * 64 + lq];
+        else if constexpr (L == St::LDS_LEVEL) return lv_lds[j * 64 + lq];
         else return R[(1 << (L - 3)) + j];
     }
-    template <int L> __device__ __forceinline__ float ld_from(int j, int src) const
+    template <int L> __device__ __forceinline__ T ld_from(int j, int src) const
     {
-        if constexpr (L == SclStore<NLOG>::GLOBAL_LEVEL) return lv_glb[j * 64 + src];
-        else if constexpr (L == SclStore<NLOG>::LDS_LEVEL) return lv_lds[j * 64 + src];
+        if constexpr (L >= St::GLOBAL_MIN) return lv_glb[(St::glb_row(L) + j) * 64 + src];
+        else if constexpr (L == St::LDS_LEVEL) return lv_lds[j * 64 + src];
         else return bperm_f(R[(1 << (L - 3)) + j], src);
     }
-    template <int L> __device__ __forceinline__ void st_own(int j, float v, int lq)
+    template <int L> __device__ __forceinline__ void st_own(int j, T v, int lq)
     {
-        if constexpr (L == SclStore<NLOG>::GLOBAL_LEVEL) lv_glb[j * 64 + lq] = v;
-        else if constexpr (L == SclStore<NLOG>::LDS_LEVEL) lv_lds[j * 64 + lq] = v;
+        if constexpr (L >= St::GLOBAL_MIN) lv_glb[(St::glb_row(L) + j) * 64 + lq] = v;
+        else if constexpr (L == St::LDS_LEVEL) lv_lds[j * 64 + lq] = v;
         else R[(1 << (L - 3)) + j] = v;
     }
     // after a level held in memory was written and before other lanes read it
     template <int L> static __device__ __forceinline__ void level_written()
     {
-        if constexpr (L == SclStore<NLOG>::GLOBAL_LEVEL) {
+        if constexpr (L >= St::GLOBAL_MIN) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        } else if constexpr (L == SclStore<NLOG>::LDS_LEVEL) {
+        } else if constexpr (L == St::LDS_LEVEL) {
             wave_sync();
         }
     }
     uint64_t a0, a1;      // plane 0 partial sums: levels with <= 32 bits per lane in a0 (offset = bit count), 64-bit level in a1
     uint64_t b0, b1;      // plane 1
     uint64_t r0, r1;      // root (S bits)
-    PathState st;
+    PathState<T> st;
     int Lcur;
     static constexpr int Lmax = LMAX;   // list size 2, 4 or 8: positions >= Lmax stay empty
 
@@ -204,15 +278,17 @@ template <int NLOG, int LMAX = 8> struct SclReg {
     // that follow a store to memory the compiler cannot tell apart would otherwise wait for it one by one (64 dependent
     // round trips at the top level instead of 4).
     // f: level LEV -> LEV-1 from my own values (or the channel at the top)
-    template <int LEV> __device__ __forceinline__ void step_f(const float *chan_lane, const LaneConst &lc)
+    static constexpr int BATCH = sizeof(T) == 4 ? 16 : 8;  // pairs in flight: 32 registers of operands either way
+    template <int LEV> __device__ __forceinline__ void step_f(const T *chan_lane, const LaneConst &lc)
     {
         constexpr int c = 1 << (LEV - 4);
-        constexpr bool MEM = LEV == NLOG || LEV == SclStore<NLOG>::GLOBAL_LEVEL || LEV == SclStore<NLOG>::LDS_LEVEL;
-        constexpr int BT = !MEM ? 1 : c < 16 ? c : 16;
+        constexpr bool MEM = LEV == NLOG || LEV >= St::GLOBAL_MIN || LEV == St::LDS_LEVEL;
+        constexpr int BT = !MEM ? 1 : c < BATCH ? c : BATCH;
         const int lq = opaque(my_lane);
+        if constexpr (LEV == NLOG) chan_lane = opaque(chan_lane);
 #pragma unroll
         for (int j0 = 0; j0 < c; j0 += BT) {
-            float a[BT], b[BT];
+            T a[BT], b[BT];
 #pragma unroll
             for (int t = 0; t < BT; t++) {
                 if constexpr (LEV == NLOG) {
@@ -225,19 +301,21 @@ template <int NLOG, int LMAX = 8> struct SclReg {
             }
 #pragma unroll
             for (int t = 0; t < BT; t++) st_own<LEV - 1>(j0 + t, f_med(a[t], b[t]), lq);
+            if constexpr (MEM && sizeof(T) == 8) __builtin_amdgcn_sched_barrier(0);  // one batch of operands in registers at a time
         }
         level_written<LEV - 1>();
         st.ownL = own_set(st.ownL, LEV - 1, (uint32_t)lc.p);
     }
     // g: operands and the left child's partial sums come from their owners' lanes
-    template <int LEV> __device__ __forceinline__ void step_g(const float *chan_lane, const LaneConst &lc)
+    template <int LEV> __device__ __forceinline__ void step_g(const T *chan_lane, const LaneConst &lc)
     {
         constexpr int c = 1 << (LEV - 4);
-        constexpr bool MEM = LEV == NLOG || LEV == SclStore<NLOG>::GLOBAL_LEVEL || LEV == SclStore<NLOG>::LDS_LEVEL;
-        constexpr int BT = MEM ? (c < 16 ? c : 16) : (c < 4 ? c : 4);  // register levels: four pairs of lane gathers in flight
+        constexpr bool MEM = LEV == NLOG || LEV >= St::GLOBAL_MIN || LEV == St::LDS_LEVEL;
+        constexpr int BT = MEM ? (c < BATCH ? c : BATCH) : (c < 4 ? c : 4);  // register levels: four pairs of lane gathers in flight
         const int srcP = (int)own_get(st.ownP, LEV - 1) * 8 + lc.q;
         const int srcL = opaque((LEV == NLOG) ? 0 : (int)own_get(st.ownL, LEV) * 8 + lc.q);
         const int lq = opaque(my_lane);
+        if constexpr (LEV == NLOG) chan_lane = opaque(chan_lane);
         uint64_t bits;
         if constexpr (c == 64) bits = bperm_u64(a1, srcP);
         else if constexpr (c >= 16) bits = (bperm_u64(a0, srcP) >> c) & (((uint64_t)1 << c) - 1);
@@ -245,7 +323,7 @@ template <int NLOG, int LMAX = 8> struct SclReg {
         // operands are level LEV, results level LEV-1: no lane overwrites what another still reads
 #pragma unroll
         for (int j0 = 0; j0 < c; j0 += BT) {
-            float a[BT], b[BT];
+            T a[BT], b[BT];
 #pragma unroll
             for (int t = 0; t < BT; t++) {
                 if constexpr (LEV == NLOG) {
@@ -258,6 +336,7 @@ template <int NLOG, int LMAX = 8> struct SclReg {
             }
 #pragma unroll
             for (int t = 0; t < BT; t++) st_own<LEV - 1>(j0 + t, g_fast(a[t], b[t], (uint32_t)(bits >> (j0 + t)) & 1u), lq);
+            if constexpr (MEM && sizeof(T) == 8) __builtin_amdgcn_sched_barrier(0);  // one batch of operands in registers at a time
         }
         level_written<LEV - 1>();
         st.ownL = own_set(st.ownL, LEV - 1, (uint32_t)lc.p);
@@ -292,7 +371,7 @@ template <int NLOG, int LMAX = 8> struct SclReg {
 
     // ---- fork / prune: position lc.p becomes (parent position `par`, bit b) ------------------------------
     // LIVE: bit I set = the g of the enclosing node I is still to come, so its saved LLR travels with the path
-    template <uint32_t LIVE> __device__ __forceinline__ void take_over(float cpm, int par, uint32_t b, const LaneConst &lc)
+    template <uint32_t LIVE> __device__ __forceinline__ void take_over(T cpm, int par, uint32_t b, const LaneConst &lc)
     {
         const int src = par * 8 + lc.q;
         st.pm = bperm_f(cpm, par * 8 + 4 * (int)b + (lc.q & 3));  // lanes q >= 4 hold the u=1 candidate metric
@@ -305,14 +384,14 @@ template <int NLOG, int LMAX = 8> struct SclReg {
 
     // One leaf.  v is the decision LLR, replicated over the 8 lanes of each path.  Returns the decided bit of
     // the path that occupies this list position afterwards.
-    template <uint32_t LIVE> __device__ __forceinline__ uint32_t leaf(float v, uint32_t is_info, const LaneConst &lc, uint32_t *surv)
+    template <uint32_t LIVE> __device__ __forceinline__ uint32_t leaf(T v, uint32_t is_info, const LaneConst &lc, uint32_t *surv)
     {
         if (!is_info) {
             st.pm += branch_metric_fast(v, 0u);
             return 0u;
         }
         const uint32_t bme = (uint32_t)lc.q >> 2;  // lanes 0..3 evaluate u = 0, lanes 4..7 evaluate u = 1
-        const float cpm = st.pm + branch_metric_fast(v, bme);
+        const T cpm = st.pm + branch_metric_fast(v, bme);
         int par;
         uint32_t b;
         if (2 * Lcur <= Lmax) {
@@ -324,14 +403,14 @@ template <int NLOG, int LMAX = 8> struct SclReg {
             // 16 candidates (p, u); my candidate is (lc.p, bme); my quad lane k compares it with 4 of the 16
             // the candidates of empty positions (list sizes below 8) rank behind every real one
             const bool alive = LMAX == 8 || lc.p < Lcur;
-            const float rpm = alive ? cpm : -INFINITY;
+            const T rpm = alive ? cpm : (T)-INFINITY;
             const int cpos = (bme ? lc.p : 8 + lc.p) + (alive ? 0 : 16);  // copies (u=1) come first in the candidate order
             const int k = lc.q & 3;
             int cnt = 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int op = 2 * k + (i >> 1), ob = i & 1;
-                const float opm = bperm_f(rpm, op * 8 + 4 * ob);
+                const T opm = bperm_f(rpm, op * 8 + 4 * ob);
                 const int opos = (ob ? op : 8 + op) + ((LMAX == 8 || op < Lcur) ? 0 : 16);
                 cnt += (opm > rpm || (opm == rpm && opos < cpos)) ? 1 : 0;
             }
@@ -356,19 +435,18 @@ template <int NLOG, int LMAX = 8> struct SclReg {
     //  3. otherwise every lane writes its per-path state, once per surviving child, into the record of the child's new
     //     position (xch[word][position * 8 + q]) and reads the record of its own position back: one write and one read
     //     instead of a survivor table followed by gathers from the parent's lanes.
-    template <uint32_t LIVE> __device__ __forceinline__ uint32_t leaf_sat(float v, const LaneConst &lc, uint32_t *xch)
+    template <uint32_t LIVE> __device__ __forceinline__ uint32_t leaf_sat(T v, const LaneConst &lc, uint32_t *xch)
     {
         const uint32_t bme = (uint32_t)lc.q >> 2;
-        const float cpm = st.pm + branch_metric_fast(v, bme);
+        const T cpm = st.pm + branch_metric_fast(v, bme);
         const bool alive = LMAX == 8 || lc.p < LMAX;
-        const float rpm = alive ? cpm : -INFINITY;
-        // ranks on integer keys with the order of the metrics (no NaN and no -0 occurs): "the other candidate wins" =
-        // its key is larger, or equal while it comes first in the candidate order, i.e. key_other > key_mine - before
-        const uint32_t rx = __float_as_uint(rpm);
-        const uint32_t key = rx ^ ((uint32_t)((int32_t)rx >> 31) | 0x80000000u);
-        uint32_t o[4];
+        const T rpm = alive ? cpm : (T)-INFINITY;
+        // ranks on integer keys with the order of the metrics: "the other candidate wins" = its key is larger, or
+        // equal while it comes first in the candidate order, i.e. key_other > key_mine - before
+        const auto key = order_key(rpm);
+        decltype(order_key(rpm)) o[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) o[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(lc.rsrc[i], (int)key);
+        for (int i = 0; i < 4; i++) o[i] = bperm_key(key, lc.rsrc[i]);
         int cnt = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) cnt += (o[i] > key - lc.rsub[i]) ? 1 : 0;
@@ -377,7 +455,7 @@ template <int NLOG, int LMAX = 8> struct SclReg {
         const bool keep = cnt == lc.p;
         constexpr uint64_t EVERY = LMAX == 8 ? 0x0101010101010101ull : LMAX == 4 ? 0x01010101ull : 0x0101ull;
         const uint64_t km = __ballot(keep);
-        const float cpm_o = dpp_mov<0x141>(cpm);  // the metric of my path's other candidate
+        const T cpm_o = dpp_mov<0x141>(cpm);  // the metric of my path's other candidate
         PROF_COUNT(22);
         if (((km | (km >> 4)) & EVERY) == EVERY) {
             PROF_COUNT(23);
@@ -386,30 +464,30 @@ template <int NLOG, int LMAX = 8> struct SclReg {
         }
         const int cnt_o = (int)dpp_mov_u32<0x141>((uint32_t)cnt);  // the rank of my path's other candidate
         const int rk[2] = {cnt, cnt_o};
-        const float mt[2] = {cpm, cpm_o};
+        const T mt[2] = {cpm, cpm_o};
 #pragma unroll
         for (int u = 0; u < 2; u++) {  // my own candidate, then my path's other one
             if (rk[u] < Lmax) {
                 uint32_t *rec = xch + rk[u] * 8 + lc.q;
-                rec[0] = __float_as_uint(mt[u]);
-                rec[64] = st.ownL;
-                rec[128] = st.ownP | lc.ubit[u];
-                int w = 3;
+                rec[0] = st.ownL;
+                rec[64] = st.ownP | lc.ubit[u];
+                int w = 2;
+                rec_put(rec, w, mt[u]);
 #pragma unroll
                 for (int i = 0; i < 3; i++)
-                    if ((LIVE >> i) & 1u) rec[64 * w++] = __float_as_uint(st.v[i]);
+                    if ((LIVE >> i) & 1u) rec_put(rec, w, st.v[i]);
             }
         }
         wave_sync();
         const uint32_t *mine = xch + lc.lane;
-        st.pm = __uint_as_float(mine[0]);
-        st.ownL = mine[64];
-        const uint32_t op = mine[128];
+        st.ownL = mine[0];
+        const uint32_t op = mine[64];
         {
-            int w = 3;
+            int w = 2;
+            rec_get(mine, w, st.pm);
 #pragma unroll
             for (int i = 0; i < 3; i++)
-                if ((LIVE >> i) & 1u) st.v[i] = __uint_as_float(mine[64 * w++]);
+                if ((LIVE >> i) & 1u) rec_get(mine, w, st.v[i]);
         }
         wave_sync();
         st.ownP = op & 0x7FFFFFFFu;
@@ -420,26 +498,26 @@ template <int NLOG, int LMAX = 8> struct SclReg {
     // are computed side by side (after the exchange for period Q the lanes of the lower half hold the left child's
     // element, the others the right child's: lane element e ends with the LLR of leaf e mod P), the P metric
     // terms in one go, and the path metric takes them in leaf order, as the leaf-by-leaf walk would.
-    template <int P> __device__ __forceinline__ void frozen_node(float v, const LaneConst &lc)
+    template <int P> __device__ __forceinline__ void frozen_node(T v, const LaneConst &lc)
     {
-        float x = v;
+        T x = v;
         if constexpr (P >= 8) {
-            const float o = partner8<8>(x);
+            const T o = partner8<8>(x);
             x = lc.up[0] ? x + o : f_fast(x, o);
         }
         if constexpr (P >= 4) {
-            const float o = partner8<4>(x);
+            const T o = partner8<4>(x);
             x = lc.up[1] ? x + o : f_fast(x, o);
         }
         {
-            const float o = partner8<2>(x);
+            const T o = partner8<2>(x);
             x = lc.up[2] ? x + o : f_fast(x, o);
         }
-        const float m = branch_metric_fast(x, 0u);
-        float t[P];
+        const T m = branch_metric_fast(x, 0u);
+        T t[P];
 #pragma unroll
         for (int i = 0; i < P; i++) t[i] = bperm_f(m, (lc.lane & ~7) + (i < 4 ? i : 11 - i));  // the lane whose element is i
-        float pm = st.pm;
+        T pm = st.pm;
 #pragma unroll
         for (int i = 0; i < P; i++) pm += t[i];
         st.pm = pm;
@@ -447,7 +525,7 @@ template <int NLOG, int LMAX = 8> struct SclReg {
 
     // A node of P leaves inside the 8-leaf subtree; v replicated with period P over the path's lanes.
     template <int P, uint32_t LIVE = 0u>
-    __device__ __forceinline__ uint32_t sub(float v, uint32_t mask, const LaneConst &lc, uint32_t *surv)
+    __device__ __forceinline__ uint32_t sub(T v, uint32_t mask, const LaneConst &lc, uint32_t *surv)
     {
         if constexpr (P == 1) {
             return leaf<LIVE>(v, mask & 1u, lc, surv);
@@ -458,14 +536,14 @@ template <int NLOG, int LMAX = 8> struct SclReg {
             }
             constexpr int I = P == 8 ? 0 : P == 4 ? 1 : 2;
             constexpr uint32_t HALF = (1u << (P / 2)) - 1u;
-            const float o = partner8<P>(v);
+            const T o = partner8<P>(v);
             st.v[I] = v;  // forks inside the left child move it along with the path
-            const float vl = f_fast(v, o);
+            const T vl = f_fast(v, o);
             const uint32_t xl = sub<P / 2, LIVE | (1u << I)>(vl, mask & HALF, lc, surv);
             st.ownL = (st.ownL & ~(1u << (XB + I))) | (xl << (XB + I));
             // g: the lanes of the lower half hold lo and apply the sign, then every lane adds its partner's value
-            const float t = flip_sign(st.v[I], xl & lc.lowmask[I]);
-            const float vr = t + partner8<P>(t);
+            const T t = flip_sign(st.v[I], xl & lc.lowmask[I]);
+            const T vr = t + partner8<P>(t);
             const uint32_t xr = sub<P / 2, LIVE>(vr, (mask >> (P / 2)) & HALF, lc, surv);
             const uint32_t xl_now = (st.ownL >> (XB + I)) & 1u;  // the left result of whoever sits here now
             return xr ^ (xl_now & lc.lowmask[I]);
@@ -475,7 +553,7 @@ template <int NLOG, int LMAX = 8> struct SclReg {
     // The same node with its rate profile known at compile time and the list full: no branch on the profile is left,
     // an all-frozen left half skips the save / restore of the node's LLR (nothing forks inside it).
     template <int P, uint32_t MASK, uint32_t LIVE = 0u>
-    __device__ __forceinline__ uint32_t sub_s(float v, const LaneConst &lc, uint32_t *surv)
+    __device__ __forceinline__ uint32_t sub_s(T v, const LaneConst &lc, uint32_t *surv)
     {
         if constexpr (MASK == 0u) {
             if constexpr (P == 1) st.pm += branch_metric_fast(v, 0u);
@@ -487,8 +565,8 @@ template <int NLOG, int LMAX = 8> struct SclReg {
             constexpr int I = P == 8 ? 0 : P == 4 ? 1 : 2;
             constexpr uint32_t HALF = (1u << (P / 2)) - 1u;
             constexpr uint32_t ML = MASK & HALF, MR = (MASK >> (P / 2)) & HALF;
-            const float o = partner8<P>(v);
-            const float vl = f_fast(v, o);
+            const T o = partner8<P>(v);
+            const T vl = f_fast(v, o);
             if constexpr (ML == 0u) {
                 if constexpr (P == 2) st.pm += branch_metric_fast(vl, 0u);
                 else frozen_node<P / 2>(vl, lc);
@@ -497,8 +575,8 @@ template <int NLOG, int LMAX = 8> struct SclReg {
                 st.v[I] = v;
                 const uint32_t xl = sub_s<P / 2, ML, LIVE | (1u << I)>(vl, lc, surv);
                 st.ownL = (st.ownL & ~(1u << (XB + I))) | (xl << (XB + I));
-                const float t = flip_sign(st.v[I], xl & lc.lowmask[I]);
-                const float vr = t + partner8<P>(t);
+                const T t = flip_sign(st.v[I], xl & lc.lowmask[I]);
+                const T vr = t + partner8<P>(t);
                 const uint32_t xr = sub_s<P / 2, MR, LIVE>(vr, lc, surv);
                 const uint32_t xl_now = (st.ownL >> (XB + I)) & 1u;
                 return xr ^ (xl_now & lc.lowmask[I]);
@@ -508,7 +586,7 @@ template <int NLOG, int LMAX = 8> struct SclReg {
 
     // An 8-leaf node: the nine rate profiles a code built from a reliability order can have here (beside all-frozen)
     // run as compiled straight-line code once the list is full, anything else through the generic form.
-    __device__ __forceinline__ uint32_t node8(float v, uint32_t m8, const LaneConst &lc, uint32_t *surv)
+    __device__ __forceinline__ uint32_t node8(T v, uint32_t m8, const LaneConst &lc, uint32_t *surv)
     {
         if (__builtin_amdgcn_readfirstlane(Lcur) == Lmax) {
             switch (m8) {
@@ -529,8 +607,8 @@ template <int NLOG, int LMAX = 8> struct SclReg {
     }
 };
 
-template <int LEV, int NLOG, int LMAX>
-__device__ __forceinline__ void scl_node(SclReg<NLOG, LMAX> &d, uint32_t maskv, const float *chan_lane, uint32_t idx, int plane,
+template <int LEV, int NLOG, int LMAX, typename T>
+__device__ __forceinline__ void scl_node(SclReg<NLOG, LMAX, T> &d, uint32_t maskv, const T *chan_lane, uint32_t idx, int plane,
                                          const LaneConst &lc, uint32_t *surv PROF_ARGS)
 {
 #pragma nounroll
@@ -548,25 +626,29 @@ __device__ __forceinline__ void scl_node(SclReg<NLOG, LMAX> &d, uint32_t maskv, 
                 d.b0 = (d.b0 & ~(uint64_t)2) | ((uint64_t)x << 1);
             } else {
                 d.a0 = (d.a0 & ~(uint64_t)2) | ((uint64_t)x << 1);
-                d.st.ownP = SclReg<NLOG, LMAX>::own_set(d.st.ownP, 3, (uint32_t)lc.p);
+                d.st.ownP = SclReg<NLOG, LMAX, T>::own_set(d.st.ownP, 3, (uint32_t)lc.p);
             }
         } else {
-            scl_node<LEV - 1, NLOG, LMAX>(d, maskv, chan_lane, cidx, (int)h, lc, surv PROF_PASS);
+            scl_node<LEV - 1, NLOG, LMAX, T>(d, maskv, chan_lane, cidx, (int)h, lc, surv PROF_PASS);
         }
     }
     d.template combine<LEV>(plane, lc);
     PROF_ADD(11);  // combines
 }
 
-template <int NLOG, int LMAX>
-__global__ void __launch_bounds__(64, 4) scl_reg_kernel(const float *__restrict__ llr, const uint32_t *__restrict__ maskw,
-                                                        const uint16_t *__restrict__ Asl8, const uint32_t *__restrict__ crcS,
-                                                        const uint32_t *__restrict__ truth, uint32_t *__restrict__ info_hat, int64_t B,
-                                                        int K, int Kw, float *__restrict__ slab)
+// List outputs (pm_out, u_hat_all; either may be NULL) are those of scl_decode_kernel: row f * LMAX + r holds the path of
+// rank r in the stable descending order of the metrics, rows of empty positions keep their index, -inf and zeros.
+template <int NLOG, int LMAX, typename T>
+__global__ void __launch_bounds__(64, sizeof(T) == 4 ? 4 : (NLOG == 8 || NLOG == 10) ? 2 : 3)
+scl_reg_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, const uint16_t *__restrict__ Asl8,
+               const uint32_t *__restrict__ crcS, const uint32_t *__restrict__ truth, uint32_t *__restrict__ info_hat, int64_t B, int K,
+               int Kw, void *__restrict__ slab, double *__restrict__ pm_out, uint32_t *__restrict__ u_hat_all)
 {
-    // exchange records of the pruning step (6 words per lane, word-major); its first words double as the survivor table of
-    // the general leaf, and the whole area as the staging buffer of the output stage (8 paths x 8 lanes x 128-bit slice of u_hat)
-    __shared__ uint32_t xchg[64 * 6];
+    // exchange records of the pruning step (6 words per lane in fp32, 10 in fp64, word-major); its first words double as the
+    // survivor table of the general leaf, and the whole area as the staging buffer of the output stage (8 paths x 8 lanes x
+    // 128-bit slice of u_hat)
+    constexpr int XW = 2 + 4 * (int)(sizeof(T) / 4);
+    __shared__ uint32_t xchg[64 * XW];
     uint32_t *const surv = xchg;
     uint32_t *const stage = xchg;
     uint32_t *const passw = xchg + 320;  // bitmap of the list entries that pass the CRC / equal the transmitted word
@@ -575,7 +657,8 @@ __global__ void __launch_bounds__(64, 4) scl_reg_kernel(const float *__restrict_
     // many wavefronts a CU holds, it is read from global memory instead
     constexpr bool ASL_LDS = NLOG < 10;
     __shared__ uint16_t asl_s[ASL_LDS ? N : 1];
-    __shared__ float lvl_s[SclStore<NLOG>::LDS_VALUES];
+    using St = SclStore<NLOG, T>;
+    __shared__ T lvl_s[St::LDS_VALUES];
     if constexpr (ASL_LDS) {
         for (int k = threadIdx.x; k < K; k += 64) asl_s[k] = Asl8[k];
         wave_sync();
@@ -605,7 +688,7 @@ __global__ void __launch_bounds__(64, 4) scl_reg_kernel(const float *__restrict_
         lc.ubit[1] = (uint32_t)(1 - bme) << 31;
     }
     const uint32_t maskv = maskw[(lc.lane & 31) < (N / 32) ? (lc.lane & 31) : 0];
-    SclReg<NLOG, LMAX> d;
+    SclReg<NLOG, LMAX, T> d;
     d.my_lane = lc.lane;
     d.lv_lds = lvl_s;
     // The level in global memory (N = 1024) lives in one of SCL_SLAB_SLOTS slabs, claimed here and given back at the end:
@@ -613,7 +696,7 @@ __global__ void __launch_bounds__(64, 4) scl_reg_kernel(const float *__restrict_
     // bitmap of claimed slabs (cleared before the launch); there are at least twice as many slabs as resident workgroups,
     // so the search below always ends.
     uint32_t slab_word = 0, slab_bit = 0;
-    if constexpr (SclStore<NLOG>::GLOBAL_VALUES > 0) {
+    if constexpr (St::GLOBAL_VALUES > 0) {
         uint32_t *bm = reinterpret_cast<uint32_t *>(slab);
         if (lc.lane == 0) {
             uint32_t w = (blockIdx.x * 5u) & (SCL_SLAB_SLOTS / 32 - 1);
@@ -635,32 +718,33 @@ __global__ void __launch_bounds__(64, 4) scl_reg_kernel(const float *__restrict_
         slab_word = (uint32_t)__builtin_amdgcn_readfirstlane((int)xchg[0]);
         slab_bit = (uint32_t)__builtin_amdgcn_readfirstlane((int)xchg[1]);
         wave_sync();
-        d.lv_glb = slab + SCL_SLAB_SLOTS / 32 + (size_t)(slab_word * 32u + slab_bit) * SclStore<NLOG>::GLOBAL_VALUES;
+        d.lv_glb = reinterpret_cast<T *>(reinterpret_cast<char *>(slab) + SCL_SLAB_SLOTS / 8) + (size_t)(slab_word * 32u + slab_bit) * St::GLOBAL_VALUES;
     } else {
-        d.lv_glb = slab;
+        d.lv_glb = reinterpret_cast<T *>(slab);
     }
 
     for (int64_t f = blockIdx.x; f < B; f += gridDim.x) {
-        const float *chan_lane = llr + f * N + lc.e;
+        const T *chan_lane = llr + f * N + lc.e;
         d.a0 = d.a1 = d.b0 = d.b1 = d.r0 = d.r1 = 0;
-        d.st.pm = 0.0f;
+        d.st.pm = (T)0;
         d.st.ownL = d.st.ownP = 0u;
 #pragma unroll
-        for (int i = 0; i < 3; i++) d.st.v[i] = 0.0f;
+        for (int i = 0; i < 3; i++) d.st.v[i] = (T)0;
         d.Lcur = 1;
         PROF_DECL;
-        scl_node<NLOG, NLOG, LMAX>(d, maskv, chan_lane, 0u, 0, lc, surv PROF_PASS);
+        scl_node<NLOG, NLOG, LMAX, T>(d, maskv, chan_lane, 0u, 0, lc, surv PROF_PASS);
 
         // final stable descending order: rank of every position; the best path is rank 0
         const bool act = lc.p < d.Lcur;
-        const float spm = act ? d.st.pm : -INFINITY;
+        const T spm = act ? d.st.pm : (T)-INFINITY;
         const int spos = act ? lc.p : 64;
         int rank = 0;
         for (int c = 0; c < 8; c++) {
-            const float opm = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(spm), c * 8));
+            const T opm = lane_value(spm, c * 8);
             const int opos = __builtin_amdgcn_readlane(spos, c * 8);
             rank += (opm > spm || (opm == spm && opos < spos)) ? 1 : 0;
         }
+        if (!act) rank = lc.p;  // rows of empty positions keep their index (all >= Lcur)
 
         // u_hat = x_hat F^{(x)n} on the sliced layout: element e + 8 j is bit j of my 128-bit root slice
         uint64_t u0 = d.r0, u1 = d.r1;
@@ -681,6 +765,21 @@ __global__ void __launch_bounds__(64, 4) scl_reg_kernel(const float *__restrict_
             stage[lc.lane * 4 + i] = w[i];
         }
         wave_sync();
+        if (pm_out && lc.q == 0 && lc.p < LMAX) pm_out[f * LMAX + rank] = (double)spm;
+        if (u_hat_all && lc.p < LMAX) {
+            // natural-order words of my path's u_hat: element 8 j + e is bit j of the slice of the lane whose element is e
+            uint32_t *row = u_hat_all + ((size_t)f * LMAX + rank) * (N / 32);
+            for (int wi = lc.q; wi < N / 32; wi += 8) {
+                uint32_t word = 0u;
+#pragma unroll 8
+                for (int t = 0; t < 32; t++) {
+                    const int e = t & 7, j = 4 * wi + (t >> 3);
+                    const uint32_t sw = stage[(lc.p * 8 + (e < 4 ? e : 11 - e)) * 4 + (j >> 5)];
+                    word |= ((sw >> (j & 31)) & 1u) << t;
+                }
+                row[wi] = act ? word : 0u;
+            }
+        }
         if (info_hat) {
             uint32_t *dst = info_hat + f * Kw;
             const uint32_t *mine = stage + lc.p * 32;
@@ -741,7 +840,7 @@ __global__ void __launch_bounds__(64, 4) scl_reg_kernel(const float *__restrict_
             for (int i = 0; i < 24; i++) atomicAdd(&g_scl_prof[i], prof_acc[i]);
 #endif
     }
-    if constexpr (SclStore<NLOG>::GLOBAL_VALUES > 0) {
+    if constexpr (St::GLOBAL_VALUES > 0) {
         // every store to the slab has landed before the next owner can claim it
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __builtin_amdgcn_wave_barrier();
@@ -764,18 +863,22 @@ extern "C" __attribute__((visibility("default"))) int polar_debug_scl_profile(un
 // ------------------------------------------------------------------------------------------ host side
 bool scl_reg_supported(const polar_code *c, int dtype, int L, const void *pm, const void *u_hat_all)
 {
-    if (dtype != POLAR_F32 || (L != 8 && L != 4 && L != 2) || pm || u_hat_all) return false;
+    if (L != 8 && L != 4 && L != 2) return false;
+    // fp32 list outputs (metrics, every path) stay with the LDS-staged kernel
+    if (dtype == POLAR_F32 ? (pm || u_hat_all) : dtype != POLAR_F64) return false;
     if (c->n < 6 || c->n > 10 || c->K < 3) return false;
     const char *e = polar_switch("POLAR_SCL_KERNEL");
     if (e && e[0] == 'l') return false;  // "lds": force the LDS-staged kernel
     return true;
 }
 
-template <int NLOG, int LMAX>
-static int launch_scl_reg_t(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, bool crc, const uint32_t *truth)
+template <int NLOG, int LMAX, typename T>
+static int launch_scl_reg_t(polar_code *c, const void *llr, uint32_t *info_hat, double *pm, uint32_t *u_hat_all, int64_t B, bool crc,
+                            const uint32_t *truth)
 {
     polar_ctx *ctx = c->ctx;
-    auto kern = scl_reg_kernel<NLOG, LMAX>;
+    using St = SclStore<NLOG, T>;
+    auto kern = scl_reg_kernel<NLOG, LMAX, T>;
     // POLAR_SCL_LDSPAD (bytes of unused dynamic LDS per wavefront) lowers the occupancy for experiments
     const char *pe = polar_switch("POLAR_SCL_LDSPAD");
     const size_t pad = pe ? (size_t)atoi(pe) : 0;
@@ -783,52 +886,64 @@ static int launch_scl_reg_t(polar_code *c, const void *llr, uint32_t *info_hat, 
     int occ = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, pad));
     if (occ < 1) occ = 1;
-    int rounds = 32;  // workgroups per resident slot: 14.9 / 16.2 / 16.8 / 17.25 M frames/s at (1024,512), L = 8, with 1 / 4 / 8 / 32
+    int rounds = 32;  // workgroups per resident slot: 14.9 / 16.2 / 16.8 / 17.25 M frames/s at (1024,512), L = 8, fp32, with 1 / 4 / 8 / 32
     if (const char *e = polar_switch("POLAR_SCL_ROUNDS")) rounds = std::max(1, atoi(e));
     int64_t grid = std::min<int64_t>(B, (int64_t)ctx->num_cus * occ * rounds);
-    // the slabs of the level that lives in global memory (N = 1024: 16 KB each) behind the bitmap of claimed ones
+    // the slabs of the levels that live in global memory (fp32, N = 1024: 16 KB each) behind the bitmap of claimed ones
     int rc;
-    if (SclStore<NLOG>::GLOBAL_VALUES > 0 && (int64_t)ctx->num_cus * occ * 2 > SCL_SLAB_SLOTS) {
+    if (St::GLOBAL_VALUES > 0 && (int64_t)ctx->num_cus * occ * 2 > SCL_SLAB_SLOTS) {
         polar_set_error("register list decoder: %d resident workgroups need more than %d slabs", ctx->num_cus * occ, SCL_SLAB_SLOTS);
         return POLAR_EUNSUPPORTED;
     }
-    const size_t slab_bytes = SclStore<NLOG>::GLOBAL_VALUES > 0 ? (SCL_SLAB_SLOTS / 32 + (size_t)SCL_SLAB_SLOTS * SclStore<NLOG>::GLOBAL_VALUES) * sizeof(float) : 4;
+    const size_t slab_bytes = St::GLOBAL_VALUES > 0 ? SCL_SLAB_SLOTS / 8 + (size_t)SCL_SLAB_SLOTS * St::GLOBAL_VALUES * sizeof(T) : 4;
     if ((rc = ctx->scl_slab.reserve(slab_bytes))) return rc;
-    if (SclStore<NLOG>::GLOBAL_VALUES > 0) HIP_TRY(hipMemsetAsync(ctx->scl_slab.p, 0, SCL_SLAB_SLOTS / 8, ctx->stream));
+    if (St::GLOBAL_VALUES > 0) HIP_TRY(hipMemsetAsync(ctx->scl_slab.p, 0, SCL_SLAB_SLOTS / 8, ctx->stream));
     LaunchTimer tm(ctx);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), pad, ctx->stream, (const float *)llr, (const uint32_t *)c->d_maskw,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), pad, ctx->stream, (const T *)llr, (const uint32_t *)c->d_maskw,
                        (const uint16_t *)c->d_Asl8, crc ? (const uint32_t *)c->d_crcS : nullptr, truth, info_hat, B, c->K, c->Kw,
-                       ctx->scl_slab.as<float>());
+                       (void *)ctx->scl_slab.p, pm, u_hat_all);
     HIP_TRY(hipGetLastError());
     float ms = tm.stop();
-    snprintf(c->last.kernel, sizeof(c->last.kernel), "scl_reg_kernel<%d>/L%d", NLOG, LMAX);
+    if (sizeof(T) == 4) snprintf(c->last.kernel, sizeof(c->last.kernel), "scl_reg_kernel<%d>/L%d", NLOG, LMAX);
+    else snprintf(c->last.kernel, sizeof(c->last.kernel), "scl_reg_kernel<%d,double>/L%d", NLOG, LMAX);
     c->last.lanes_per_frame = 64;
-    c->last.lds_bytes_per_block = 1536 + (NLOG < 10 ? 2 * c->N : 2) + 4 * SclStore<NLOG>::LDS_VALUES;
+    c->last.lds_bytes_per_block = 64 * 4 * (2 + 4 * (int)(sizeof(T) / 4)) + (NLOG < 10 ? 2 * c->N : 2) + (int)sizeof(T) * St::LDS_VALUES;
     c->last.block_threads = 64;
     c->last.grid_blocks = (int)grid;
     c->last.last_ms = ms;
     return POLAR_OK;
 }
 
-template <int NLOG> static int launch_scl_reg_l(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, bool crc, const uint32_t *truth, int L)
+template <int NLOG, typename T>
+static int launch_scl_reg_l(polar_code *c, const void *llr, uint32_t *info_hat, double *pm, uint32_t *u_hat_all, int64_t B, bool crc,
+                            const uint32_t *truth, int L)
 {
     switch (L) {
-    case 8: return launch_scl_reg_t<NLOG, 8>(c, llr, info_hat, B, crc, truth);
-    case 4: return launch_scl_reg_t<NLOG, 4>(c, llr, info_hat, B, crc, truth);
-    case 2: return launch_scl_reg_t<NLOG, 2>(c, llr, info_hat, B, crc, truth);
+    case 8: return launch_scl_reg_t<NLOG, 8, T>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
+    case 4: return launch_scl_reg_t<NLOG, 4, T>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
+    case 2: return launch_scl_reg_t<NLOG, 2, T>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
     default: polar_set_error("register SCL kernel: list size must be 2, 4 or 8"); return POLAR_EUNSUPPORTED;
     }
 }
 
-int launch_scl_reg(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, bool crc, const uint32_t *truth, int L)
+template <typename T>
+static int launch_scl_reg_n(polar_code *c, const void *llr, uint32_t *info_hat, double *pm, uint32_t *u_hat_all, int64_t B, bool crc,
+                            const uint32_t *truth, int L)
 {
-    if (B == 0) return POLAR_OK;
     switch (c->n) {
-    case 6: return launch_scl_reg_l<6>(c, llr, info_hat, B, crc, truth, L);
-    case 7: return launch_scl_reg_l<7>(c, llr, info_hat, B, crc, truth, L);
-    case 8: return launch_scl_reg_l<8>(c, llr, info_hat, B, crc, truth, L);
-    case 9: return launch_scl_reg_l<9>(c, llr, info_hat, B, crc, truth, L);
-    case 10: return launch_scl_reg_l<10>(c, llr, info_hat, B, crc, truth, L);
+    case 6: return launch_scl_reg_l<6, T>(c, llr, info_hat, pm, u_hat_all, B, crc, truth, L);
+    case 7: return launch_scl_reg_l<7, T>(c, llr, info_hat, pm, u_hat_all, B, crc, truth, L);
+    case 8: return launch_scl_reg_l<8, T>(c, llr, info_hat, pm, u_hat_all, B, crc, truth, L);
+    case 9: return launch_scl_reg_l<9, T>(c, llr, info_hat, pm, u_hat_all, B, crc, truth, L);
+    case 10: return launch_scl_reg_l<10, T>(c, llr, info_hat, pm, u_hat_all, B, crc, truth, L);
     default: polar_set_error("register SCL kernel: unsupported length"); return POLAR_EUNSUPPORTED;
     }
+}
+
+int launch_scl_reg(polar_code *c, const void *llr, int dtype, uint32_t *info_hat, double *pm, uint32_t *u_hat_all, int64_t B, bool crc,
+                   const uint32_t *truth, int L)
+{
+    if (B == 0) return POLAR_OK;
+    if (dtype == POLAR_F32) return launch_scl_reg_n<float>(c, llr, info_hat, pm, u_hat_all, B, crc, truth, L);
+    return launch_scl_reg_n<double>(c, llr, info_hat, pm, u_hat_all, B, crc, truth, L);
 }

@@ -114,7 +114,8 @@ int launch_sc_big(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B)
 void sc_big_release(polar_code *c);
 bool scl_reg_supported(const polar_code *c, int dtype, int L, const void *pm, const void *u_hat_all);
 // truth (packed [B x Kw], or NULL): genie-aided choice of the output path
-int launch_scl_reg(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, bool crc, const uint32_t *truth, int L);
+int launch_scl_reg(polar_code *c, const void *llr, int dtype, uint32_t *info_hat, double *pm, uint32_t *u_hat_all, int64_t B, bool crc,
+                   const uint32_t *truth, int L);
 // the two-lanes-per-path register kernel for L = 16 / 32 (plain list decoding, best path only)
 bool scl_wide_supported(const polar_code *c, int dtype, int L, const void *pm, const void *u_hat_all);
 int launch_scl_wide(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, int L, bool crc, const uint32_t *truth);

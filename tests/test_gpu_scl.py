@@ -212,3 +212,31 @@ def test_scl_wide_kernel_equals_lds_kernel(monkeypatch, cons, N, K, L):
     b, _, _ = code.scl_decode(llr, L)
     assert code.last_launch()["kernel"].startswith("scl_decode_kernel")
     assert np.array_equal(a, b), np.flatnonzero(np.any(a != b, axis=1))[:20]
+
+
+@pytest.mark.parametrize("L", [8, 4, 2])
+@pytest.mark.parametrize("N,K", [(64, 32), (128, 64), (256, 128), (512, 256), (1024, 512), (1024, 300), (256, 200)])
+def test_scl_fp64_register_kernel_equals_lds_kernel(monkeypatch, N, K, L):
+    """fp64, the reference's arithmetic: the register-resident kernel against the LDS-staged kernel, whole sorted list.
+    Both evaluate f, g and the metric expression in the same order, so decoded bits, every survivor and every path metric
+    must be identical to the last bit -- including frames with integer LLRs, where candidate metrics tie exactly."""
+    mask = pcf.degaBuild(N, K, 2.0)
+    code = _native.Code(_native.default_ctx(), mask)
+    rs = np.random.RandomState(N + K + L)
+    B = 701
+    x = oracle.polar_encode(rs.randint(0, 2, size=(B, K)), mask).reshape(B, N)
+    n0 = 1.0 / (K / N * 10 ** (1.0 / 10))
+    llr = code.channel_llr(x, n0, 17, 0, np.float64)
+    llr[:40] = np.round(llr[:40])
+    llr[40:44] *= 200.0  # metrics of wrong decisions overflow to -inf
+    monkeypatch.delenv("POLAR_SCL_KERNEL", raising=False)
+    a, apm, auh = code.scl_decode(llr, L, want_list=True)
+    assert code.last_launch()["kernel"].startswith("scl_reg_kernel") and "double" in code.last_launch()["kernel"], code.last_launch()
+    a2, _, _ = code.scl_decode(llr, L)  # without the list outputs
+    monkeypatch.setenv("POLAR_SCL_KERNEL", "lds")
+    b, bpm, buh = code.scl_decode(llr, L, want_list=True)
+    assert code.last_launch()["kernel"].startswith("scl_decode_kernel")
+    assert np.array_equal(a, b), np.flatnonzero(np.any(a != b, axis=1))[:20]
+    assert np.array_equal(a2, b)
+    assert np.array_equal(auh, buh), np.flatnonzero(np.any(auh != buh, axis=(1, 2)))[:20]
+    assert np.array_equal(apm, bpm), np.flatnonzero(np.any(apm != bpm, axis=1))[:20]
