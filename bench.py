@@ -419,7 +419,6 @@ def main():
             extras["sc_fp64_parity_mode"] = {"frames_per_s": nb / (li["last_ms"] * 1e-3), "info_mbps": nb * K / (li["last_ms"] * 1e-3) / 1e6,
                                              "kernel": li["kernel"], "kernel_ms": li["last_ms"], "frames": nb,
                                              "roofline": leg_roofline(li["kernel"], li["last_ms"], nb, N, K, hbm_bytes_per_frame=8 * N + K / 8)}
-            nb = 1 << 14
             pm64 = torch.empty((nb, 8), dtype=torch.float64, device=dev)
             for _ in range(2):
                 code.scl_decode_dev(l64.data_ptr(), np.float64, 8, h64.data_ptr(), nb, pm_ptr=pm64.data_ptr())

@@ -636,10 +636,13 @@ __device__ __forceinline__ void scl_node(SclReg<NLOG, LMAX, T> &d, uint32_t mask
     PROF_ADD(11);  // combines
 }
 
+#ifndef POLAR_SCL64_TWO
+#define POLAR_SCL64_TWO 99  // fp64: the length (log2) that runs two wavefronts per SIMD without spilling rather than three with
+#endif
 // List outputs (pm_out, u_hat_all; either may be NULL) are those of scl_decode_kernel: row f * LMAX + r holds the path of
 // rank r in the stable descending order of the metrics, rows of empty positions keep their index, -inf and zeros.
 template <int NLOG, int LMAX, typename T>
-__global__ void __launch_bounds__(64, sizeof(T) == 4 ? 4 : (NLOG == 8 || NLOG == 10) ? 2 : 3)
+__global__ void __launch_bounds__(64, sizeof(T) == 4 ? 4 : (NLOG == 8 || NLOG == POLAR_SCL64_TWO) ? 2 : 3)
 scl_reg_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, const uint16_t *__restrict__ Asl8,
                const uint32_t *__restrict__ crcS, const uint32_t *__restrict__ truth, uint32_t *__restrict__ info_hat, int64_t B, int K,
                int Kw, void *__restrict__ slab, double *__restrict__ pm_out, uint32_t *__restrict__ u_hat_all)

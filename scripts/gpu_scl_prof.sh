@@ -2,19 +2,20 @@
 export POLAR_EXPERIMENT=1  # the library reads its kernel switches only with this set
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
 for V in ${VARIANTS:-reg1 reg}; do
-POLAR_HIP_LIB=$R/polar-codes_amd/libpolar_hip_prof.so POLAR_SCL_KERNEL=$V timeout -k 10 200 python3 - <<'PY' || exit 1
+POLAR_HIP_LIB=${PROF_LIB:-$R/polar-codes_amd/libpolar_hip_prof.so} POLAR_SCL_KERNEL=$V timeout -k 10 200 python3 - <<'PY' || exit 1
 import sys, os, ctypes; sys.path[:0]=['polar-codes_amd','.']
 import numpy as np, torch, _native, functions as pcf
 from channel import Channel
 ctx=_native.default_ctx(0); ctx.enable_timing(True)
 L_=_native.lib()
 N,K,L,snr,nb=int(os.environ.get('PN','1024')),int(os.environ.get('PK','512')),8,2.0,1<<18
+dt=np.float64 if os.environ.get('PDT','f32')=='f64' else np.float32; tdt=torch.float64 if dt is np.float64 else torch.float32
 code=_native.Code(ctx,pcf.degaBuild(N,K,2.0)); n0=Channel('BPSK',snr,'SNRb',K/N).noisePower
-llr=torch.empty((nb,N),dtype=torch.float32,device='cuda'); hat=torch.empty((nb,code.Kw),dtype=torch.int32,device='cuda')
-code.gen_frames_dev(None,llr.data_ptr(),np.float32,n0,1,0,nb)
-code.scl_decode_dev(llr.data_ptr(),np.float32,L,hat.data_ptr(),nb); ctx.sync()
+llr=torch.empty((nb,N),dtype=tdt,device='cuda'); hat=torch.empty((nb,code.Kw),dtype=torch.int32,device='cuda')
+code.gen_frames_dev(None,llr.data_ptr(),dt,n0,1,0,nb)
+code.scl_decode_dev(llr.data_ptr(),dt,L,hat.data_ptr(),nb); ctx.sync()
 buf=(ctypes.c_ulonglong*24)(); L_.polar_debug_scl_profile(buf,1)
-code.scl_decode_dev(llr.data_ptr(),np.float32,L,hat.data_ptr(),nb); ctx.sync()
+code.scl_decode_dev(llr.data_ptr(),dt,L,hat.data_ptr(),nb); ctx.sync()
 li=code.last_launch(); L_.polar_debug_scl_profile(buf,1)
 v=np.array(list(buf),dtype=np.float64)/nb
 names={i:'f/g level %d'%i for i in range(4,11)}; print('saturated info leaves per frame %.1f, of which nothing moved %.1f'%(v[22],v[23])); v[22]=v[23]=0; names[11]='combine'; names[21]='output'
