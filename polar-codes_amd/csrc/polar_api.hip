@@ -306,6 +306,55 @@ static const int64_t HOST_CHUNK = 1 << 14;
 
 static size_t llr_size(int dtype) { return dtype == POLAR_F64 ? sizeof(double) : sizeof(float); }
 
+// LLRs handed over in host memory: the batch crosses the link in chunks through two staging buffers, chunk i+1 on the
+// context's second stream while chunk i is decoded on the first (with page-locked host memory the copies are asynchronous
+// and the link stays busy; from pageable memory the copy call itself blocks, but the decode launched before it runs
+// meanwhile).  Outputs go back on the decode stream behind their kernel; the caller synchronises once, after the loop.
+struct HostLlrFeed {
+    polar_ctx *ctx = nullptr;
+    const char *host = nullptr;
+    size_t frame_bytes = 0;
+    int64_t B = 0, chunk = 0;
+    void *buf[2] = {nullptr, nullptr};
+    int64_t nchunks() const { return (B + chunk - 1) / chunk; }
+    int begin(polar_ctx *x, const void *llr, size_t fb, int64_t nframes, int64_t per)
+    {
+        ctx = x, host = (const char *)llr, frame_bytes = fb, B = nframes, chunk = std::min(per, nframes);
+        int rc;
+        if ((rc = ctx->llr_buf.reserve(chunk * frame_bytes))) return rc;
+        if (nchunks() > 1 && (rc = ctx->mc_llr2.reserve(chunk * frame_bytes))) return rc;
+        buf[0] = ctx->llr_buf.p, buf[1] = nchunks() > 1 ? ctx->mc_llr2.p : ctx->llr_buf.p;
+        // the copies must not overtake work queued earlier on the context's stream (it may still read the buffers)
+        HIP_TRY(hipEventRecord(ctx->dec_done[1], ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->gen_stream, ctx->dec_done[1], 0));
+        return copy(0);
+    }
+    int copy(int64_t idx)
+    {
+        const int b = (int)(idx & 1);
+        const int64_t b0 = idx * chunk, nb = std::min(chunk, B - b0);
+        // buffer b was last read by the decode of chunk idx - 2
+        if (idx >= 2) HIP_TRY(hipStreamWaitEvent(ctx->gen_stream, ctx->dec_done[b], 0));
+        HIP_TRY(hipMemcpyAsync(buf[b], host + b0 * frame_bytes, nb * frame_bytes, hipMemcpyHostToDevice, ctx->gen_stream));
+        HIP_TRY(hipEventRecord(ctx->gen_done[b], ctx->gen_stream));
+        return POLAR_OK;
+    }
+    // device address of chunk idx; the decode stream waits for its copy
+    int take(int64_t idx, const char **p)
+    {
+        const int b = (int)(idx & 1);
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->gen_done[b], 0));
+        *p = (const char *)buf[b];
+        return POLAR_OK;
+    }
+    // after the decode of chunk idx has been queued: mark its buffer's last reader and start the next copy
+    int decoded(int64_t idx)
+    {
+        HIP_TRY(hipEventRecord(ctx->dec_done[idx & 1], ctx->stream));
+        return idx + 1 < nchunks() ? copy(idx + 1) : POLAR_OK;
+    }
+};
+
 #define CHECK_COMMON(code, B, space)                                                      \
     ARG_TRY((code) != nullptr, "code is NULL");                                           \
     ARG_TRY((B) >= 0, "B must be >= 0");                                                  \
@@ -428,22 +477,24 @@ static int sc_common(polar_code *c, const void *llr, int dtype, void *info_hat, 
         return launch_sc_decode(c, llr, dtype, (uint32_t *)info_hat, (uint32_t *)u_hat, dec_llr, B, flags);
     int rc;
     const int64_t chunk = (space == POLAR_HOST) ? HOST_CHUNK : (int64_t)1 << 20;
-    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+    HostLlrFeed feed;
+    if (space == POLAR_HOST && (rc = feed.begin(ctx, llr, c->N * es, B, chunk))) return rc;
+    int64_t idx = 0;
+    for (int64_t b0 = 0; b0 < B; b0 += chunk, idx++) {
         int64_t nb = std::min(chunk, B - b0);
         const char *dl = (const char *)llr + b0 * c->N * es;
         char *ddec = dec_llr ? (char *)dec_llr + b0 * c->N * es : nullptr;
         if ((rc = ctx->out_words.reserve(nb * c->Kw * 4)) || (rc = ctx->aux_buf.reserve(nb * c->Nw * 4))) return rc;
         uint32_t *wi = ctx->out_words.as<uint32_t>(), *wu = u_hat ? ctx->aux_buf.as<uint32_t>() : nullptr;
         if (space == POLAR_HOST) {
-            if ((rc = ctx->llr_buf.reserve(nb * c->N * es))) return rc;
-            HIP_TRY(hipMemcpyAsync(ctx->llr_buf.p, dl, nb * c->N * es, hipMemcpyHostToDevice, ctx->stream));
-            dl = ctx->llr_buf.as<char>();
             if (dec_llr) {
                 if ((rc = ctx->aux2_buf.reserve(nb * c->N * es))) return rc;
                 ddec = ctx->aux2_buf.as<char>();
             }
+            if ((rc = feed.take(idx, &dl))) return rc;
         }
         if ((rc = launch_sc_decode(c, dl, dtype, wi, wu, ddec, nb, flags))) return rc;
+        if (space == POLAR_HOST && (rc = feed.decoded(idx))) return rc;
         if (packed) {  // host + packed
             if (info_hat) HIP_TRY(hipMemcpyAsync((uint32_t *)info_hat + b0 * c->Kw, wi, nb * c->Kw * 4, hipMemcpyDeviceToHost, ctx->stream));
             if (u_hat) HIP_TRY(hipMemcpyAsync((uint32_t *)u_hat + b0 * c->Nw, wu, nb * c->Nw * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -466,11 +517,10 @@ static int sc_common(polar_code *c, const void *llr, int dtype, void *info_hat, 
                 if (u_hat && (rc = launch_unpack_bits(ctx, wu, bu + b0 * c->N, nb, c->N))) return rc;
             }
         }
-        if (space == POLAR_HOST) {
-            if (dec_llr) HIP_TRY(hipMemcpyAsync((char *)dec_llr + b0 * c->N * es, ddec, nb * c->N * es, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
-        }
+        if (space == POLAR_HOST && dec_llr)
+            HIP_TRY(hipMemcpyAsync((char *)dec_llr + b0 * c->N * es, ddec, nb * c->N * es, hipMemcpyDeviceToHost, ctx->stream));
     }
+    if (space == POLAR_HOST) HIP_TRY(hipStreamSynchronize(ctx->stream));
     return POLAR_OK;
 }
 
@@ -500,9 +550,13 @@ static int scl_common(polar_code *c, const void *llr, int dtype, int L, void *in
     const size_t es = llr_size(dtype);
     if (space == POLAR_DEVICE && packed)
         return launch_scl_decode(c, llr, dtype, L, (uint32_t *)info_hat, pm, (uint32_t *)u_hat_all, B, crc, (const uint32_t *)truth);
-    int rc;
-    const int64_t chunk = (space == POLAR_HOST) ? std::max<int64_t>(1, HOST_CHUNK / L) : (int64_t)1 << 18;
-    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+    int rc = POLAR_OK;
+    // the whole list as an output takes L code words per frame of staging: fewer frames per chunk then
+    const int64_t chunk = (space == POLAR_HOST) ? (u_hat_all ? std::max<int64_t>(1, HOST_CHUNK / L) : HOST_CHUNK) : (int64_t)1 << 18;
+    HostLlrFeed feed;
+    if (space == POLAR_HOST && (rc = feed.begin(ctx, llr, c->N * es, B, chunk))) return rc;
+    int64_t idx = 0;
+    for (int64_t b0 = 0; b0 < B; b0 += chunk, idx++) {
         int64_t nb = std::min(chunk, B - b0);
         const char *dl = (const char *)llr + b0 * c->N * es;
         if ((rc = ctx->out_words.reserve(nb * c->Kw * 4)) || (rc = ctx->aux_buf.reserve(nb * L * c->Nw * 4)) ||
@@ -510,11 +564,7 @@ static int scl_common(polar_code *c, const void *llr, int dtype, int L, void *in
             return rc;
         uint32_t *wi = ctx->out_words.as<uint32_t>(), *wu = u_hat_all ? ctx->aux_buf.as<uint32_t>() : nullptr;
         double *dpm = pm ? (space == POLAR_HOST ? ctx->pm_buf.as<double>() : pm + b0 * L) : nullptr;
-        if (space == POLAR_HOST) {
-            if ((rc = ctx->llr_buf.reserve(nb * c->N * es))) return rc;
-            HIP_TRY(hipMemcpyAsync(ctx->llr_buf.p, dl, nb * c->N * es, hipMemcpyHostToDevice, ctx->stream));
-            dl = ctx->llr_buf.as<char>();
-        }
+        if (space == POLAR_HOST && (rc = feed.take(idx, &dl))) return rc;
         const uint32_t *wt = nullptr;
         if (truth) {
             if (packed && space == POLAR_DEVICE) {
@@ -536,6 +586,7 @@ static int scl_common(polar_code *c, const void *llr, int dtype, int L, void *in
             }
         }
         if ((rc = launch_scl_decode(c, dl, dtype, L, wi, dpm, wu, nb, crc, wt))) return rc;
+        if (space == POLAR_HOST && (rc = feed.decoded(idx))) return rc;
         if (packed) {
             if (info_hat) HIP_TRY(hipMemcpyAsync((uint32_t *)info_hat + b0 * c->Kw, wi, nb * c->Kw * 4, hipMemcpyDeviceToHost, ctx->stream));
             if (u_hat_all) HIP_TRY(hipMemcpyAsync((uint32_t *)u_hat_all + b0 * L * c->Nw, wu, nb * L * c->Nw * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -558,11 +609,9 @@ static int scl_common(polar_code *c, const void *llr, int dtype, int L, void *in
                 if (u_hat_all && (rc = launch_unpack_bits(ctx, wu, bu + b0 * L * c->N, nb * L, c->N))) return rc;
             }
         }
-        if (space == POLAR_HOST) {
-            if (pm) HIP_TRY(hipMemcpyAsync(pm + b0 * L, dpm, nb * L * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
-        }
+        if (space == POLAR_HOST && pm) HIP_TRY(hipMemcpyAsync(pm + b0 * L, dpm, nb * L * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     }
+    if (space == POLAR_HOST) HIP_TRY(hipStreamSynchronize(ctx->stream));
     return POLAR_OK;
 }
 
@@ -718,16 +767,17 @@ static int pbf_common(polar_code *c, const void *llr, int dtype, int max_level, 
     const size_t es = llr_size(dtype);
     int rc;
     const int64_t chunk = (space == POLAR_HOST) ? HOST_CHUNK : (int64_t)1 << 22;
-    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+    HostLlrFeed feed;
+    if (space == POLAR_HOST && (rc = feed.begin(ctx, llr, c->N * es, B, chunk))) return rc;
+    int64_t idx = 0;
+    for (int64_t b0 = 0; b0 < B; b0 += chunk, idx++) {
         const int64_t nb = std::min(chunk, B - b0);
         const char *dl = (const char *)llr + b0 * c->N * es;
         uint32_t *wi;
         int32_t *d_runs = runs ? runs + b0 : nullptr, *d_last = last_seq ? last_seq + b0 * 3 : nullptr;
         uint8_t *d_ok = crc_ok ? crc_ok + b0 : nullptr;
         if (space == POLAR_HOST) {
-            if ((rc = ctx->llr_buf.reserve(nb * c->N * es)) || (rc = ctx->flip_small.reserve(nb * 17))) return rc;
-            HIP_TRY(hipMemcpyAsync(ctx->llr_buf.p, dl, nb * c->N * es, hipMemcpyHostToDevice, ctx->stream));
-            dl = ctx->llr_buf.as<char>();
+            if ((rc = ctx->flip_small.reserve(nb * 17)) || (rc = feed.take(idx, &dl))) return rc;
             d_runs = ctx->flip_small.as<int32_t>();
             d_last = d_runs + nb;
             d_ok = reinterpret_cast<uint8_t *>(d_last + 3 * nb);
@@ -739,6 +789,7 @@ static int pbf_common(polar_code *c, const void *llr, int dtype, int max_level, 
             wi = ctx->out_words.as<uint32_t>();
         }
         if ((rc = pbf_device(c, dl, dtype, max_level, wi, d_runs, d_ok, d_last, nb))) return rc;
+        if (space == POLAR_HOST && (rc = feed.decoded(idx))) return rc;
         if (packed) {
             if (space == POLAR_HOST)
                 HIP_TRY(hipMemcpyAsync((uint32_t *)info_hat + b0 * c->Kw, wi, nb * c->Kw * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -753,9 +804,9 @@ static int pbf_common(polar_code *c, const void *llr, int dtype, int max_level, 
             if (runs) HIP_TRY(hipMemcpyAsync(runs + b0, d_runs, nb * 4, hipMemcpyDeviceToHost, ctx->stream));
             if (last_seq) HIP_TRY(hipMemcpyAsync(last_seq + b0 * 3, d_last, nb * 12, hipMemcpyDeviceToHost, ctx->stream));
             if (crc_ok) HIP_TRY(hipMemcpyAsync(crc_ok + b0, d_ok, nb, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
         }
     }
+    if (space == POLAR_HOST) HIP_TRY(hipStreamSynchronize(ctx->stream));
     return POLAR_OK;
 }
 

@@ -46,12 +46,13 @@ struct polar_ctx {
     int timing = 0;
     bool overlapped = false;  // a second stream of this context has kernels in flight (the staged Monte-Carlo loop)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // Monte-Carlo pipeline: frames of chunk i+1 are generated on gen_stream while chunk i is decoded
+    // Monte-Carlo pipeline: frames of chunk i+1 are generated on gen_stream while chunk i is decoded; host-space decoder
+    // calls copy chunk i+1 of the caller's LLRs on it the same way
     hipStream_t gen_stream = nullptr;
     hipEvent_t gen_done[2] = {nullptr, nullptr}, dec_done[2] = {nullptr, nullptr};
     // staging / scratch
     DevBuf in_bytes, out_bytes, in_words, out_words, llr_buf, aux_buf, aux2_buf, pm_buf, counters, mc_info, mc_hat, scl_slab;
-    DevBuf mc_llr2, mc_info2;  // second buffers of the Monte-Carlo pipeline
+    DevBuf mc_llr2, mc_info2;  // second buffers of the Monte-Carlo pipeline (mc_llr2 also of the host-space LLR feed)
     DevBuf flip_rows, flip_ctr, flip_small;  // failing-frame list, {work counter, row count}, per-frame side outputs
     DevBuf flip_pairs;                       // two-flip search: frames, best pairs and ranked first flips of the frames it works on
 };
