@@ -20,7 +20,7 @@ def main():
             continue
         k, v = m.group(1).strip(), m.group(2)
         if k == "Function Name":
-            cur = subprocess.run(["c++filt", v], capture_output=True, text=True).stdout.strip().split("(")[0]
+            cur = subprocess.run(["c++filt", v], capture_output=True, text=True).stdout.strip().replace("(anonymous namespace)::", "").split("(")[0]
             rows[cur] = {}
         elif cur:
             rows[cur][k] = v
