@@ -7,10 +7,10 @@ import sys; sys.path[:0]=['$R/polar-codes_amd','$R']
 import numpy as np, torch, _native, functions as pcf
 from channel import Channel
 ctx=_native.default_ctx(0)
-def frames(mask, nb, snr=2.0, crc=False, Kmsg=None):
+def frames(mask, nb, snr=2.0, crc=False, Kmsg=None, tdt=torch.float32):
     N=len(mask); K=int(mask.sum()); code=_native.Code(ctx,mask)
     n0=Channel('BPSK',snr,'SNRb',(Kmsg or K)/N).noisePower
-    llr=torch.empty((nb,N),dtype=torch.float32,device='cuda'); info=torch.zeros((nb,code.Kw),dtype=torch.int32,device='cuda'); hat=torch.empty_like(info)
+    llr=torch.empty((nb,N),dtype=tdt,device='cuda'); info=torch.zeros((nb,code.Kw),dtype=torch.int32,device='cuda'); hat=torch.empty_like(info)
     return code, n0, llr, info, hat
 code,n0,llr,info,hat=frames(pcf.degaBuild(1024,512,2.0),1<<19); code.gen_frames_dev(info.data_ptr(),llr.data_ptr(),np.float32,n0,1,0,1<<19)
 for _ in range(2): code.scl_decode_dev(llr.data_ptr(),np.float32,8,hat.data_ptr(),1<<19)
@@ -21,6 +21,11 @@ for _ in range(2): code.sc_decode_dev(llr.data_ptr(),np.float32,hat.data_ptr(),1
 code,n0,llr,info,hat=frames(pcf.degaBuild(1024,536,2.0),1<<18,Kmsg=512); code.set_crc(0x1800063); code.set_reliability(pcf.GA(1024,536,2.0))
 code.gen_frames_dev(info.data_ptr(),llr.data_ptr(),np.float32,n0,1,0,1<<18,crc=True)
 for _ in range(2): code.pbf_decode_dev(llr.data_ptr(),np.float32,2,hat.data_ptr(),1<<18)
+# the reference's arithmetic (fp64): every-leaf SC with decision LLRs, list decoder with the sorted list's metrics
+code,n0,llr,info,hat=frames(pcf.degaBuild(1024,512,2.0),1<<17,tdt=torch.float64); code.gen_frames_dev(info.data_ptr(),llr.data_ptr(),np.float64,n0,1,0,1<<17)
+dl=torch.empty_like(llr); pm=torch.empty((1<<17,8),dtype=torch.float64,device='cuda')
+for _ in range(2): code.sc_decode_dev(llr.data_ptr(),np.float64,hat.data_ptr(),1<<17,fast=False,dec_llr_ptr=dl.data_ptr())
+for _ in range(2): code.scl_decode_dev(llr.data_ptr(),np.float64,8,hat.data_ptr(),1<<17,pm_ptr=pm.data_ptr())
 ctx.sync()
 PY
 rm -rf $R/gpurun_out/prof_legs; timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_legs -- python3 /tmp/legs.py > $R/gpurun_out/prof_legs.log 2>&1 || { tail -5 $R/gpurun_out/prof_legs.log; exit 1; }
@@ -31,7 +36,8 @@ done
 cp $R/gpurun_out/prof_legs/*/*kernel_stats.csv $R/gpurun_out/legs_kernel_stats.csv
 python3 - <<PY
 import csv,glob,collections,json
-legs={'scl_reg_kernel':(1<<19,4*1024+64,'(1024,512) L=8'),'scl_wide_kernel':(1<<17,4*512+32,'rmpolar (512,256) L=32'),'sc_big_kernel':(1<<15,4*16384+1024,'(16384,8192) SC'),
+legs={'scl_reg_kernel<10, 8, float>':(1<<19,4*1024+64,'(1024,512) L=8'),'scl_reg_kernel<10, 8, double>':(1<<17,8*1024+64,'(1024,512) L=8 fp64, sorted metrics out'),
+      'sc_reg_full_kernel<double, 10>':(1<<17,16*1024+64,'(1024,512) SC fp64, every leaf, decision LLRs out'),'scl_wide_kernel':(1<<17,4*512+32,'rmpolar (512,256) L=32'),'sc_big_kernel':(1<<15,4*16384+1024,'(16384,8192) SC'),
       'pbf_reg_kernel<float, 10, 0>':(1<<18,None,'(1024,536) CRC-24 flip search, single flips, 2^18 frames in the batch'),
       'pbf_reg_kernel<float, 10, 1>':(1<<18,None,'same, pair search'),'sc_static':(0,0,'')}
 agg=collections.defaultdict(lambda: collections.defaultdict(list))
