@@ -317,6 +317,14 @@ struct HostLlrFeed {
     int64_t B = 0, chunk = 0;
     void *buf[2] = {nullptr, nullptr};
     int64_t nchunks() const { return (B + chunk - 1) / chunk; }
+    // the caller's buffers belong to the caller again when the call returns, also when it returns an error half-way:
+    // nothing that reads or writes them is left in flight (after a call that succeeded both streams are idle already)
+    ~HostLlrFeed()
+    {
+        if (!ctx) return;
+        (void)hipStreamSynchronize(ctx->gen_stream);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
     int begin(polar_ctx *x, const void *llr, size_t fb, int64_t nframes, int64_t per)
     {
         ctx = x, host = (const char *)llr, frame_bytes = fb, B = nframes, chunk = std::min(per, nframes);
