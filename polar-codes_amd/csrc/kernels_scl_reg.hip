@@ -121,6 +121,21 @@ __device__ __forceinline__ float branch_metric_fast(float v, uint32_t u)
     return e >= 1024.0f ? -INFINITY : r;
 }
 
+// A lower bound of |e| (e the exponent in the branch metric of decision LLR v) for the price of one multiplication, and
+// whether |e| is so large that the extension agreeing with the sign of v adds exactly 1 to its path's metric: 2^-|e| then
+// vanishes beside 1 in the metric's arithmetic (below half a unit in the last place), the logarithm is that of exactly 1.
+__device__ __forceinline__ bool sure_exponent(float v, float &ae_lo)
+{
+    ae_lo = fabsf(v * 1.44269504088896340736f);  // the metric's own |e|
+    return ae_lo >= 25.0f;
+}
+__device__ __forceinline__ bool sure_exponent(double v, double &ae_lo)
+{
+    const double a = fabs(v);
+    ae_lo = a * 1.4426950408889;  // the metric divides by ln 2: this constant is below 1 / ln 2 by more than any rounding
+    return a >= 37.5;             // |v| / ln 2 >= 54.1
+}
+
 constexpr int SCL_SLAB_SLOTS = 8192;  // slabs for the level in global memory: at least twice the resident workgroups
 
 // Small per-path state that moves between lane groups at a fork.
@@ -429,6 +444,7 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
 
     // The same leaf once the list is full (every later information bit prunes 2 Lmax candidates to Lmax), as
     // straight-line code with as few dependent trips through the LDS crossbar as the data flow allows:
+    //  0. leaves that every path is sure of are recognised from the LLRs and the metrics alone (see the block below);
     //  1. the four metrics a lane ranks its candidate against arrive together;
     //  2. when every path's better candidate keeps the path's own list position (the common case at reliable bits)
     //     nothing moves between lane groups: a wave-uniform test on the ranks ends the leaf there;
@@ -438,6 +454,26 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
     template <uint32_t LIVE> __device__ __forceinline__ uint32_t leaf_sat(T v, const LaneConst &lc, uint32_t *xch)
     {
         const uint32_t bme = (uint32_t)lc.q >> 2;
+        {
+            // 0. A leaf every path is sure of ends before any metric is evaluated.  If |e| is large in every path, each
+            //    path's agreeing extension has the metric pm + 1 exactly and its other extension at most pm + 2 - |e| (its
+            //    term is 1 - |e| up to rounding far below the 1 of margin; rounding is monotone, so the bound holds for the
+            //    rounded sums as well).  If then the agreeing extensions are in strictly falling order by list position and
+            //    every other extension lies strictly below the last of them, the ranking below would find each agreeing
+            //    extension at its path's own position and take the exit of step 2 with these very metrics.
+            T ae_lo;
+            const bool big = sure_exponent(v, ae_lo);
+            const T cpm_a = st.pm + (T)1;
+            const T next = bperm_f(cpm_a, lc.lane + 8);  // the agreeing extension of the next list position
+            const T other = st.pm + ((T)2 - ae_lo);
+            const T last = lane_value(cpm_a, 8 * (LMAX - 1));
+            const bool sure = big && other < last && (lc.p == LMAX - 1 || cpm_a > next);
+            if (__ballot(sure || (LMAX < 8 && lc.p >= LMAX)) == ~0ull) {
+                PROF_COUNT(0);
+                st.pm = cpm_a;
+                return v < (T)0 ? 1u : 0u;
+            }
+        }
         const T cpm = st.pm + branch_metric_fast(v, bme);
         const bool alive = LMAX == 8 || lc.p < LMAX;
         const T rpm = alive ? cpm : (T)-INFINITY;
