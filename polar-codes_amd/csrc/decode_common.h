@@ -76,3 +76,26 @@ __device__ __forceinline__ uint32_t butterfly_word(uint32_t x, int n)
     return x;
 }
 
+
+// ---- list decoders: information leaves every path is sure of --------------------------------------------------------
+// The branch metric of deciding u at decision LLR v is 1 - log2(1 + 2^e), e = (u ? v : -v) / ln 2 (cn/polarCode.py:982-988).
+// sure_exponent gives a lower bound of |e| for the price of one multiplication and says whether |e| is so large that the
+// extension agreeing with the sign of v adds exactly 1 to its path's metric in the metric's own arithmetic: 2^-|e| is then
+// below half a unit in the last place of 1, the sum is exactly 1 and its logarithm exactly 0.  The other extension then adds
+// 1 - |e| up to rounding, at most 2 - |e| (lower bound of |e|) with a margin no rounding reaches, and since rounding is
+// monotone the bound holds for the rounded sums as well.  A list decoder uses this on a full list: if in every path |e| is
+// that large, the agreeing extensions pm + 1 are in strictly falling order by list position, and every other extension's
+// bound pm + (2 - |e|) lies strictly below the last of them, then the stable ranking of the 2L candidates puts each path's
+// agreeing extension at the path's own position: no path moves, every metric grows by exactly 1, and the leaf is decided
+// without evaluating a metric or ranking anything -- the same bits and metrics, not an approximation.
+__device__ __forceinline__ bool sure_exponent(float v, float &ae_lo)
+{
+    ae_lo = fabsf(v * 1.44269504088896340736f);  // the fp32 metric's own |e|
+    return ae_lo >= 25.0f;
+}
+__device__ __forceinline__ bool sure_exponent(double v, double &ae_lo)
+{
+    const double a = fabs(v);
+    ae_lo = a * 1.4426950408889;  // the fp64 metric divides by ln 2: this constant is below 1 / ln 2 by more than any rounding
+    return a >= 37.5;             // |v| / ln 2 >= 54.1
+}

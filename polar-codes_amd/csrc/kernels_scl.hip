@@ -206,11 +206,31 @@ __global__ void __launch_bounds__(64) scl_decode_kernel(SCLParams<T> p, const ui
             }
             case OP_LEAF_INFO: {
                 T v = tree(ptr_get(ptrL, 0))[1];
-                // lane `sub` evaluates the metric of deciding (sub & 1); even/odd lanes of a group swap
-                T bm_mine = branch_metric(v, sub & 1);
-                T bm0 = shfl_real(bm_mine, grp * G), bm1 = shfl_real(bm_mine, grp * G + 1);
                 uint32_t bit;
-                if (2 * Lcur <= L) {
+                bool decided = false;
+                if (2 * Lcur > L) {
+                    // full list: a leaf every path is sure of is decided before any metric is evaluated or ranked
+                    // (sure_exponent in decode_common.h has the argument)
+                    T ae_lo;
+                    const bool big = sure_exponent(v, ae_lo);
+                    const T cpm_a = pm + (T)1;
+                    const T next = shfl_real(cpm_a, lane + G < 64 ? lane + G : lane);  // the agreeing extension of the next list position
+                    const T last = bcast_real(cpm_a, (L - 1) * G);
+                    const bool sure = big && pm + ((T)2 - ae_lo) < last && (grp == L - 1 || cpm_a > next);
+                    if (__ballot(sure) == ~0ull) {
+                        pm = cpm_a;
+                        bit = v < (T)0 ? 1u : 0u;
+                        decided = true;
+                    }
+                }
+                // lane `sub` evaluates the metric of deciding (sub & 1); even/odd lanes of a group swap
+                T bm_mine = (T)0, bm0 = (T)0, bm1 = (T)0;
+                if (!decided) {
+                    bm_mine = branch_metric(v, sub & 1);
+                    bm0 = shfl_real(bm_mine, grp * G), bm1 = shfl_real(bm_mine, grp * G + 1);
+                }
+                if (decided) {
+                } else if (2 * Lcur <= L) {
                     // list = originals ++ copies
                     const bool is_copy = grp >= Lcur && grp < 2 * Lcur;
                     const int src = is_copy ? (grp - Lcur) * G + sub : lane;

@@ -121,21 +121,6 @@ __device__ __forceinline__ float branch_metric_fast(float v, uint32_t u)
     return e >= 1024.0f ? -INFINITY : r;
 }
 
-// A lower bound of |e| (e the exponent in the branch metric of decision LLR v) for the price of one multiplication, and
-// whether |e| is so large that the extension agreeing with the sign of v adds exactly 1 to its path's metric: 2^-|e| then
-// vanishes beside 1 in the metric's arithmetic (below half a unit in the last place), the logarithm is that of exactly 1.
-__device__ __forceinline__ bool sure_exponent(float v, float &ae_lo)
-{
-    ae_lo = fabsf(v * 1.44269504088896340736f);  // the metric's own |e|
-    return ae_lo >= 25.0f;
-}
-__device__ __forceinline__ bool sure_exponent(double v, double &ae_lo)
-{
-    const double a = fabs(v);
-    ae_lo = a * 1.4426950408889;  // the metric divides by ln 2: this constant is below 1 / ln 2 by more than any rounding
-    return a >= 37.5;             // |v| / ln 2 >= 54.1
-}
-
 constexpr int SCL_SLAB_SLOTS = 8192;  // slabs for the level in global memory: at least twice the resident workgroups
 
 // Small per-path state that moves between lane groups at a fork.
@@ -455,12 +440,9 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
     {
         const uint32_t bme = (uint32_t)lc.q >> 2;
         {
-            // 0. A leaf every path is sure of ends before any metric is evaluated.  If |e| is large in every path, each
-            //    path's agreeing extension has the metric pm + 1 exactly and its other extension at most pm + 2 - |e| (its
-            //    term is 1 - |e| up to rounding far below the 1 of margin; rounding is monotone, so the bound holds for the
-            //    rounded sums as well).  If then the agreeing extensions are in strictly falling order by list position and
-            //    every other extension lies strictly below the last of them, the ranking below would find each agreeing
-            //    extension at its path's own position and take the exit of step 2 with these very metrics.
+            // 0. A leaf every path is sure of ends before any metric is evaluated (sure_exponent in decode_common.h has the
+            //    argument): the ranking below would find each agreeing extension at its path's own position and take the exit
+            //    of step 2 with these very metrics.
             T ae_lo;
             const bool big = sure_exponent(v, ae_lo);
             const T cpm_a = st.pm + (T)1;

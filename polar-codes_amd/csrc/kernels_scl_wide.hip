@@ -298,18 +298,16 @@ template <int NLOG, int LMAX> struct WideDec {
             return 0u;
         }
         if (2 * Lcur > LMAX) {
-            // The list is full.  A leaf every path is sure of ends before any metric is evaluated or ranked: if |e| >= 25 in
-            // every path, each path's agreeing extension has the metric pm + 1 exactly (2^-|e| vanishes beside 1, the logarithm
-            // is that of exactly 1) and its other extension pm + (1 - |e|), below pm + (2 - |e|) with a margin no rounding
-            // reaches; rounding is monotone, so the bound holds for the rounded sums.  If the agreeing extensions are in
-            // strictly falling order by list position and every other extension lies strictly below the last of them, the
-            // ranking below gives each position its own path's agreeing extension with this very metric, and nothing moves.
-            const float ae = fabsf(v * 1.44269504088896340736f);  // the metric's own |e|
+            // The list is full.  A leaf every path is sure of ends before any metric is evaluated or ranked (sure_exponent in
+            // decode_common.h has the argument): the ranking below would give each position its own path's agreeing extension
+            // with this very metric, and nothing would move.
+            float ae;
+            const bool big = sure_exponent(v, ae);
             const float cpm_a = pm + 1.0f;
             const float next = wb_f(cpm_a, lane + 2);  // the agreeing extension of the next list position
             const float other = pm + (2.0f - ae);
             const float last = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cpm_a), 2 * (LMAX - 1)));
-            const bool sure = ae >= 25.0f && other < last && (p == LMAX - 1 || cpm_a > next);
+            const bool sure = big && other < last && (p == LMAX - 1 || cpm_a > next);
             if (__ballot(sure || (LMAX < 32 && p >= LMAX)) == ~0ull) {
                 pm = cpm_a;
                 return v < 0.0f ? 1u : 0u;
