@@ -190,6 +190,46 @@ def test_scl8_headline_kernel_vs_fp32_oracle(monkeypatch, snr):
     assert (~same).sum() <= 0.01 * B
 
 
+@pytest.mark.parametrize("snr", [1.0, 2.0])
+def test_scl32_rate_profiled_512_kernel_vs_fp32_oracle(monkeypatch, snr):
+    """The rate-profiled (512,256) code with L = 32 in fp32 -- the configuration that stresses sort and prune -- straight
+    against the fp32 oracle, frame by frame, with the margin argument of the test above: the device-vs-host difference of the
+    metrics is measured on the lists the LDS-staged kernel returns, every frame whose closest pair of competing metrics is
+    further apart than twice that must decode to the oracle's bits on the two-lanes-per-path register kernel."""
+    N, K, L, B = 512, 256, 32, 768
+    mask = pcf.rmPolarBuild(N, K, 2.0)
+    code = _native.Code(_native.default_ctx(), mask)
+    rs = np.random.RandomState(100 + int(snr * 10))
+    x = oracle.polar_encode(rs.randint(0, 2, size=(B, K)), mask).reshape(B, N)
+    n0 = 1.0 / (K / N * 10 ** (snr / 10))
+    llr = code.channel_llr(x, n0, 77 + int(snr), 0, np.float32)
+    monkeypatch.delenv("POLAR_SCL_KERNEL", raising=False)
+    got, _, _ = code.scl_decode(llr, L)
+    assert code.last_launch()["kernel"].startswith("scl_wide_kernel<9>/L32"), code.last_launch()
+    monkeypatch.setenv("POLAR_SCL_KERNEL", "lds")
+    lds, pm, uh = code.scl_decode(llr, L, want_list=True)
+    assert np.array_equal(got, lds)
+    ref = np.empty_like(got)
+    gap = np.empty(B)
+    err = 0.0
+    for b in range(B):
+        ruh, rpm, _ = oracle.scl_decode(llr[b], mask, L)
+        gap[b] = oracle.scl_last_min_gap()
+        ref[b] = oracle.extract(ruh[0], mask)
+        if np.array_equal(uh[b], ruh):
+            fin = np.isfinite(rpm)
+            assert np.array_equal(np.isfinite(pm[b]), fin)
+            err = max(err, float(np.max(np.abs(pm[b][fin] - rpm[fin]) / np.maximum(np.abs(rpm[fin]), 1.0), initial=0.0)))
+    margin = 2.0 * err
+    same = np.all(got == ref, axis=1)
+    inside = gap <= margin
+    print(f"\nSCL-32 rmpolar (512,256) {snr} dB: device-vs-host metric difference {err:.3g} (relative), margin {margin:.3g}; "
+          f"{int(inside.sum())} of {B} frames inside it, {int((~same).sum())} frames decoded differently")
+    assert err < 1e-5
+    assert same[~inside].all(), np.flatnonzero(~same & ~inside)[:10]
+    assert (~same).sum() <= 0.02 * B
+
+
 @pytest.mark.parametrize("L", [32, 16])
 @pytest.mark.parametrize("cons,N,K", [("dega", 64, 32), ("dega", 128, 64), ("dega", 256, 128), ("dega", 512, 256), ("rmpolar", 512, 256),
                                       ("dega", 512, 150), ("dega", 256, 200), ("dega", 1024, 512), ("dega", 1024, 820)])
