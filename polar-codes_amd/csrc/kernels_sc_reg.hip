@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(64, 4) sc_reg_kernel(const T *__restrict__ llr
 
         sc_reg_epilogue_c<NLOG>(d.root, stage, ctab_s, rc, info_hat, fc, active, lane, K, Kw, truth, nbits, &acc);
     }
-    if (truth) err_acc_flush(acc, counters);
+    if (truth) err_acc_flush<1>(acc, counters, nullptr);
 }
 
 // The every-leaf walk with the reference's side outputs: u_hat (packed, natural order) and the decision LLRs of all N

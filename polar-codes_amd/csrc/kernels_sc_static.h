@@ -414,12 +414,34 @@ template <int NLOG> struct GatherShape {
 struct ErrAcc {
     uint32_t be = 0, fe = 0, fr = 0;
 };
-__device__ __forceinline__ void err_acc_flush(const ErrAcc &a, unsigned long long *counters)
+// The sums of a wavefront (its four counting lanes are the first of each row), in every lane.
+__device__ __forceinline__ ErrAcc err_acc_wave(const ErrAcc &a)
 {
-    if (a.fr) {
-        atomicAdd(&counters[0], (unsigned long long)a.fr);
-        if (a.fe) atomicAdd(&counters[1], (unsigned long long)a.fe);
-        if (a.be) atomicAdd(&counters[2], (unsigned long long)a.be);
+    ErrAcc w;
+    w.be = w.fe = w.fr = 0u;
+#pragma unroll
+    for (int r = 0; r < 64; r += 16) {
+        w.be += (uint32_t)__builtin_amdgcn_readlane((int)a.be, r);
+        w.fe += (uint32_t)__builtin_amdgcn_readlane((int)a.fe, r);
+        w.fr += (uint32_t)__builtin_amdgcn_readlane((int)a.fr, r);
+    }
+    return w;
+}
+// Adds to the global counters once per workgroup: every atomic of a launch lands on the same cache line, where they are
+// served one after the other (a few nanoseconds each), so a launch should bring thousands of them, not millions.
+// block3: three words of LDS that were zero at the workgroup's first barrier (unused by workgroups of one wavefront).
+// Every thread of the workgroup must call this.
+template <int WAVES> __device__ __forceinline__ void err_acc_flush(const ErrAcc &a, unsigned long long *counters, uint32_t *block3)
+{
+    const ErrAcc w = err_acc_wave(a);
+    const int l = threadIdx.x & 63;
+    const uint32_t mine = l == 0 ? w.fr : (l == 1 ? w.fe : w.be);  // lanes 0, 1, 2 of a wavefront carry frames, frame errors, bit errors
+    if constexpr (WAVES == 1) {
+        if (l < 3 && mine) atomicAdd(&counters[l], (unsigned long long)mine);
+    } else {
+        if (l < 3 && mine) atomicAdd(&block3[l], mine);
+        __syncthreads();
+        if (threadIdx.x < 3 && block3[threadIdx.x]) atomicAdd(&counters[threadIdx.x], (unsigned long long)block3[threadIdx.x]);
     }
 }
 
@@ -655,7 +677,9 @@ extern "C" __global__ void __launch_bounds__(64 * SC_STATIC_WAVES, POLAR_STATIC_
     __shared__ __attribute__((aligned(32))) uint32_t stage_s[SC_STATIC_WAVES * SC_STAGE_WORDS];
     __shared__ __attribute__((aligned(16))) uint32_t ctab_s[256];
     __shared__ float kept_s[SC_STATIC_WAVES * (KEPT > 0 ? KEPT : 1)];
+    __shared__ uint32_t count_s[3];
     for (int k = threadIdx.x; k < 256; k += 64 * SC_STATIC_WAVES) ctab_s[k] = ctab[k];
+    if (threadIdx.x < 3) count_s[threadIdx.x] = 0u;
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: frame offsets stay in scalar registers
     const int lane = threadIdx.x & 63;
@@ -680,7 +704,7 @@ extern "C" __global__ void __launch_bounds__(64 * SC_STATIC_WAVES, POLAR_STATIC_
         decode_static<PolarStaticProfile, NLOG, 0, 0>(d, llr + fc * N + sub, rc);
         sc_reg_epilogue_c<NLOG>(d.root, stage, ctab_s, rc, info_hat, fc, active, lane, K, Kw, truth, nbits, &acc);
     }
-    if (truth) err_acc_flush(acc, counters);
+    if (truth) err_acc_flush<SC_STATIC_WAVES>(acc, counters, count_s);
 }
 
 #if POLAR_STATIC_NLOG >= 7  // a Philox block spans four slice elements: below N = 128 a lane has fewer pairs than that
@@ -702,7 +726,9 @@ extern "C" __global__ void __launch_bounds__(64 * SC_STATIC_WAVES, POLAR_STATIC_
     __shared__ __attribute__((aligned(32))) uint32_t stage_s[SC_STATIC_WAVES * SC_STAGE_WORDS];
     __shared__ uint16_t asl_s[GatherShape<NLOG>::WORDS];
     __shared__ float kept_s[SC_STATIC_WAVES * (KEPT > 0 ? KEPT : 1)];
+    __shared__ uint32_t count_s[3];
     for (int k = threadIdx.x; k < GatherShape<NLOG>::WORDS; k += 64 * SC_STATIC_WAVES) asl_s[k] = Asl[k];
+    if (threadIdx.x < 3) count_s[threadIdx.x] = 0u;
     __syncthreads();
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -785,7 +811,7 @@ extern "C" __global__ void __launch_bounds__(64 * SC_STATIC_WAVES, POLAR_STATIC_
             acc.fr += 1u;
         }
     }
-    err_acc_flush(acc, counters);
+    err_acc_flush<SC_STATIC_WAVES>(acc, counters, count_s);
 }
 #endif
 #endif
