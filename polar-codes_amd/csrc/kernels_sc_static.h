@@ -778,7 +778,9 @@ extern "C" __global__ void __launch_bounds__(64 * SC_STATIC_WAVES, POLAR_STATIC_
             const uint32_t goff = (uint32_t)grp << 2;
 #pragma unroll
             for (int s = 0; s < 2; s++) {
-                if (s == 0 || (TW > 16 && Kw > 16)) {
+                // only lanes that drew a word take part: an LDS atomic costs by the lanes it serves, and short codes have
+                // few information words per frame
+                if ((s == 0 || (TW > 16 && Kw > 16)) && sub + 16 * s < Kw) {
                     const uint16_t *t = asl_s + sub + 16 * s;
 #pragma unroll
                     for (int i = 0; i < 32; i++) {
