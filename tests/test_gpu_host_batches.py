@@ -78,3 +78,43 @@ def test_host_flip_search_of_several_chunks_equals_resident_batch():
     words = hat.cpu().numpy().view(np.uint32)
     want = ((words[:, np.arange(K) >> 5] >> (np.arange(K) & 31).astype(np.uint32)) & 1).astype(np.uint8)
     assert np.array_equal(info, want) and np.array_equal(r, runs.cpu().numpy()) and r.max() > 1
+
+
+def test_host_calls_interleaved_with_the_monte_carlo_pipeline(monkeypatch):
+    """Host-space decoder calls and the staged Monte-Carlo loop share the context's second stream, its events and the two
+    LLR staging buffers: interleaved in any order, on the context's own stream or on one the caller set, each gives what it
+    gives alone."""
+    N, K = 256, 128
+    ctx = _native.default_ctx(0)
+    code = _native.Code(ctx, pcf.degaBuild(N, K, 2.0))
+    lib = _native.lib()
+    dev, pinned, pageable = _frames(code, N, K, np.float32)
+    n0 = Channel("BPSK", 1.5, "SNRb", K / N).noisePower
+    monkeypatch.setenv("POLAR_MC_KERNEL", "staged")
+    monkeypatch.setenv("POLAR_MC_CHUNK", "20000")  # several chunks: the loop's two-buffer path
+    dt = _native._dt(np.float32)
+
+    def host_scl(src):
+        got = np.zeros((B, code.Kw), dtype=np.int32)
+        _native._check(lib.polar_scl_decode_packed(code._h, src, dt, 4, got.ctypes.data, None, None, B, 0, _native.HOST))
+        return got
+
+    def host_sc(src):
+        got = np.zeros((B, code.Kw), dtype=np.int32)
+        _native._check(lib.polar_sc_decode_packed(code._h, src, dt, got.ctypes.data, None, None, B, _native.SC_FAST, _native.HOST))
+        return got
+
+    want_scl, want_sc = host_scl(pinned.data_ptr()), host_sc(pageable.ctypes.data)
+    want_mc = code.mc_run(_native.DEC_SCL, 4, np.float32, n0, 3, 0, 70000).tolist()
+    side = torch.cuda.Stream()
+    for stream in (None, side):
+        ctx.set_stream(stream.cuda_stream if stream is not None else None)
+        try:
+            for _ in range(2):
+                assert np.array_equal(host_scl(pageable.ctypes.data), want_scl)
+                assert code.mc_run(_native.DEC_SCL, 4, np.float32, n0, 3, 0, 70000).tolist() == want_mc
+                assert np.array_equal(host_sc(pinned.data_ptr()), want_sc)
+                assert code.mc_run(_native.DEC_SC, 1, np.float32, n0, 3, 0, 70000)[0] == 70000
+                assert np.array_equal(host_scl(pinned.data_ptr()), want_scl)
+        finally:
+            ctx.set_stream(None)
