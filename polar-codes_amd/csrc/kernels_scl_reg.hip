@@ -450,6 +450,14 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
             const T other = st.pm + ((T)2 - ae_lo);
             const T last = lane_value(cpm_a, 8 * (LMAX - 1));
             const bool sure = big && other < last && (lc.p == LMAX - 1 || cpm_a > next);
+#ifdef POLAR_SCL_PROFILE
+            {   // why a leaf goes on to the ranking: some LLR small (1), else another extension could survive (2), else order (3)
+                const bool dead = LMAX < 8 && lc.p >= LMAX;
+                if (__ballot(big || dead) != ~0ull) PROF_COUNT(1);
+                else if (__ballot(other < last || dead) != ~0ull) PROF_COUNT(2);
+                else if (__ballot(sure || dead) != ~0ull) PROF_COUNT(3);
+            }
+#endif
             if (__ballot(sure || (LMAX < 8 && lc.p >= LMAX)) == ~0ull) {
                 PROF_COUNT(0);
                 st.pm = cpm_a;

@@ -18,7 +18,7 @@ buf=(ctypes.c_ulonglong*24)(); L_.polar_debug_scl_profile(buf,1)
 code.scl_decode_dev(llr.data_ptr(),dt,L,hat.data_ptr(),nb); ctx.sync()
 li=code.last_launch(); L_.polar_debug_scl_profile(buf,1)
 v=np.array(list(buf),dtype=np.float64)/nb
-names={i:'f/g level %d'%i for i in range(4,11)}; print('information leaves of a full list that reach the ranking, per frame, %.1f, of which nothing moved %.1f; decided before any metric %.1f'%(v[22],v[23],v[0])); v[22]=v[23]=v[0]=0; names[11]='combine'; names[21]='output'
+names={i:'f/g level %d'%i for i in range(4,11)}; print('information leaves of a full list that reach the ranking, per frame, %.1f, of which nothing moved %.1f; decided before any metric %.1f (not: some LLR small %.1f, another extension could survive %.1f, order %.1f)'%(v[22],v[23],v[0],v[1],v[2],v[3])); v[22]=v[23]=v[0]=v[1]=v[2]=v[3]=0; names[11]='combine'; names[21]='output'
 for i in range(12,21): names[i]='node8 with %d info'%(i-12)
 tot=v.sum()
 print(os.environ.get('POLAR_SCL_KERNEL'),li['kernel'],'Mframes/s %.2f'%(nb/(li['last_ms']*1e-3)/1e6),'cycles/frame %.0f'%tot)
