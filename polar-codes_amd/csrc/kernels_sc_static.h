@@ -612,8 +612,9 @@ __device__ __forceinline__ void sc_reg_words_c(ps_t root, uint32_t *out, const u
     auto place = [&](uint32_t piece, uint32_t e) {
         const uint64_t v = (uint64_t)piece << (e >> 16);
         uint32_t *dst = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(row) + (e & 0xFFFFu));
-        atomicOr(dst, (uint32_t)v);
-        atomicOr(dst + 1, (uint32_t)(v >> 32));
+        // an LDS atomic costs by the lanes it serves: empty pieces and pieces that end inside their first word stay out
+        if ((uint32_t)v) atomicOr(dst, (uint32_t)v);
+        if ((uint32_t)(v >> 32)) atomicOr(dst + 1, (uint32_t)(v >> 32));
     };
     place(lo & 0xFFFFu, c2.z);
     if constexpr (NLOG > 8) place(lo >> 16, c2.w);
