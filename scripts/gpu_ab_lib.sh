@@ -1,3 +1,6 @@
+# Two builds of the library side by side on one box (box-to-box spread is +-3 %): polar-codes_amd/libpolar_ab_base.so is a build of
+# the tree to compare against (make, then copy libpolar_hip.so under that name), the in-tree library is the other; three
+# alternating runs of the 10^7-frame step, then the lengths-and-rates table for both.
 export POLAR_EXPERIMENT=1
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
 for rep in 1 2 3; do

@@ -1,3 +1,4 @@
+"""One-kernel Monte-Carlo loop (polar_mc_run on a specialised code) at four code lengths: frames per second and counters."""
 import sys, os, time
 sys.path[:0] = ['.', 'polar-codes_amd']
 import numpy as np

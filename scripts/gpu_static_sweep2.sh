@@ -1,3 +1,4 @@
+# specialised SC decoder: channel pairs kept in registers / in LDS, each setting twice and interleaved so that drift shows
 export POLAR_EXPERIMENT=1
 for CFG in "16 16 4" "20 12 4" "24 8 4" "18 14 4" "16 16 4" "20 12 4" "24 8 4" "18 14 4"; do
   set -- $CFG
