@@ -104,10 +104,17 @@ extern "C" int polar_comm_init_all(int ndev, const int *devices, polar_comm **ou
         delete c;
         return POLAR_EHIP;
     }
-    c->streams.resize(ndev);
+    c->streams.assign(ndev, nullptr);
     for (int i = 0; i < ndev; i++) {
-        HIP_TRY(hipSetDevice(c->devices[i]));
-        HIP_TRY(hipStreamCreateWithFlags(&c->streams[i], hipStreamNonBlocking));
+        // a failure here gives back the communicators and the streams made so far (polar_comm_destroy skips null entries)
+        hipError_t e = hipSetDevice(c->devices[i]);
+        if (e == hipSuccess) e = polar_fault_at("comm_init") ? hipErrorOutOfMemory : hipStreamCreateWithFlags(&c->streams[i], hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            c->streams[i] = nullptr;
+            polar_set_error("stream for device %d: %s", c->devices[i], hipGetErrorString(e));
+            (void)polar_comm_destroy(c);
+            return POLAR_EHIP;
+        }
     }
     *out = c;
     return POLAR_OK;
@@ -138,11 +145,27 @@ extern "C" int polar_allreduce_counters(polar_comm *c, uint64_t *const *dev_coun
     for (int i = 0; i < ndev; i++) ARG_TRY(dev_counters[i] != nullptr, "NULL counter buffer");
     // work queued on the devices' default streams (e.g. by polar_ctx_sync'ed decoder calls) has to be finished by the caller
     RCCL_TRY(g_rccl.GroupStart());
-    for (int i = 0; i < ndev; i++) {
-        HIP_TRY(hipSetDevice(c->devices[i]));
-        RCCL_TRY(g_rccl.AllReduce(dev_counters[i], dev_counters[i], (size_t)n, NCCL_UINT64, NCCL_SUM, c->comms[i], c->streams[i]));
+    // once the group is open every path reaches GroupEnd: an open group would swallow this thread's later collectives
+    int rc = POLAR_OK;
+    for (int i = 0; i < ndev && rc == POLAR_OK; i++) {
+        const hipError_t e = hipSetDevice(c->devices[i]);
+        if (e != hipSuccess) {
+            polar_set_error("hipSetDevice(%d) failed: %s", c->devices[i], hipGetErrorString(e));
+            rc = POLAR_EHIP;
+            break;
+        }
+        const ncclResult_t r = polar_fault_at("allreduce") ? 1 : g_rccl.AllReduce(dev_counters[i], dev_counters[i], (size_t)n, NCCL_UINT64, NCCL_SUM, c->comms[i], c->streams[i]);
+        if (r != 0) {
+            polar_set_error("ncclAllReduce on device %d failed: %s", c->devices[i], g_rccl.GetErrorString(r));
+            rc = POLAR_EHIP;
+        }
     }
-    RCCL_TRY(g_rccl.GroupEnd());
+    const ncclResult_t rend = g_rccl.GroupEnd();
+    if (rc != POLAR_OK) return rc;  // the message of the first failure stays
+    if (rend != 0) {
+        polar_set_error("ncclGroupEnd failed: %s", g_rccl.GetErrorString(rend));
+        return POLAR_EHIP;
+    }
     for (int i = 0; i < ndev; i++) {
         HIP_TRY(hipSetDevice(c->devices[i]));
         HIP_TRY(hipStreamSynchronize(c->streams[i]));

@@ -121,6 +121,11 @@ __device__ __forceinline__ float branch_metric_fast(float v, uint32_t u)
     return e >= 1024.0f ? -INFINITY : r;
 }
 
+__device__ __forceinline__ float fabs_t(float v) { return __builtin_fabsf(v); }
+__device__ __forceinline__ double fabs_t(double v) { return __builtin_fabs(v); }
+__device__ __forceinline__ float fmin_t(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ double fmin_t(double a, double b) { return __builtin_fmin(a, b); }
+
 constexpr int SCL_SLAB_SLOTS = 8192;  // slabs for the level in global memory: at least twice the resident workgroups
 
 // Small per-path state that moves between lane groups at a fork.
@@ -133,6 +138,20 @@ template <typename T> struct PathState {
 };
 
 constexpr int XB = 24;
+
+// Largest subtrees (log2 of their leaves) decoded as one unit: all-frozen ones, and all-information ones every path is sure
+// of.  The register allocation of the N = 1024 kernel sits at its limit of 128; larger units (up to 6 is written) spill.
+#ifndef POLAR_SCL_FROZEN_TOP
+#define POLAR_SCL_FROZEN_TOP 4
+#endif
+#ifndef POLAR_SCL_SURE_TOP
+#define POLAR_SCL_SURE_TOP 3
+#endif
+// plain decoding (no CRC, no genie): the output stage gathers the best path's information bits only, over all 64 lanes
+#ifndef POLAR_SCL_BEST_GATHER
+#define POLAR_SCL_BEST_GATHER 1
+#endif
+
 
 // -DPOLAR_SCL_PROFILE: per-category wall-clock cycles of the register list decoder, summed over wavefronts
 // (development aid; scripts/gpu_scl_prof.sh builds a second library with it)
@@ -549,6 +568,129 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
         st.pm = pm;
     }
 
+    // ---- whole subtrees of 16, 32 or 64 leaves decoded as one unit --------------------------------------------------
+    // The partial sums of a finished subtree of level LV (2^(LV-3) bits per lane) go to plane `plane` like a combine's.
+    template <int LV> __device__ __forceinline__ void put_sums(int plane, uint64_t x, const LaneConst &lc)
+    {
+        constexpr int CB = 1 << (LV - 3);
+        if (plane) {
+            set_bits<CB>(b0, b1, x);
+        } else {
+            set_bits<CB>(a0, a1, x);
+            st.ownP = own_set(st.ownP, LV, (uint32_t)lc.p);
+        }
+    }
+    // All 2^LV leaves frozen: every decision is 0, so nothing forks, no owner changes and no partial sum is ever non-zero:
+    // g is hi + lo everywhere.  The decision LLRs of all leaves are computed side by side (register j of the lane ends as
+    // the 8-leaf node j of the subtree, whose three bottom stages are frozen_node's exchanges) with the operations the
+    // leaf-by-leaf walk performs, and the metric takes the 2^LV terms in leaf order.
+    template <int LV> __device__ __forceinline__ void frozen_subtree(int plane, const LaneConst &lc)
+    {
+        constexpr int C = 1 << (LV - 3);
+        T *const x = R + C;  // the subtree's own level: dead once its leaves are decided, so the work happens in place
+#pragma unroll
+        for (int m = LV; m > 3; m--) {
+            const int h = 1 << (m - 4);
+#pragma unroll
+            for (int blk = 0; blk < C; blk += 2 * h)
+#pragma unroll
+                for (int t = 0; t < h; t++) {
+                    const T a = x[blk + t], b = x[blk + h + t];
+                    x[blk + t] = f_med(a, b);
+                    x[blk + h + t] = b + a;
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < C; j++) {
+            T o = partner8<8>(x[j]);
+            x[j] = lc.up[0] ? x[j] + o : f_fast(x[j], o);
+            o = partner8<4>(x[j]);
+            x[j] = lc.up[1] ? x[j] + o : f_fast(x[j], o);
+            o = partner8<2>(x[j]);
+            x[j] = lc.up[2] ? x[j] + o : f_fast(x[j], o);
+            x[j] = branch_metric_fast(x[j], 0u);
+        }
+        T pm = st.pm;
+#pragma unroll
+        for (int j = 0; j < C; j++) {
+#pragma unroll
+            for (int i0 = 0; i0 < 8; i0 += 4) {
+                T t[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) t[i] = bperm_f(x[j], (lc.lane & ~7) + (i0 + i < 4 ? i0 + i : 11 - i0 - i));
+#pragma unroll
+                for (int i = 0; i < 4; i++) pm += t[i];
+            }
+        }
+        st.pm = pm;
+        put_sums<LV>(plane, 0, lc);
+    }
+    // All 2^LV leaves carry information and the list is full.  With hard decisions on its LLRs (the decisions SC makes in
+    // such a node) every LLR below has at least the magnitude of the smallest of them: f takes a minimum, g adds two values
+    // of equal sign.  If that smallest magnitude passes sure_exponent's test in every path, the paths' metrics are apart
+    // by more than DELTA in list order, and every path's metric plus (2 - |e|) stays more than DELTA + 1 below the last
+    // path's, then the three conditions of leaf_sat's first step hold at each of the 2^LV leaves in turn (the metrics all
+    // grow by 1 per leaf; DELTA is far above what 64 rounded additions to numbers below 4096 can drift): no path moves,
+    // each metric takes 2^LV additions of 1, and the node's partial sums are the signs of its LLRs.  Exact, like the
+    // per-leaf test; returns false (and changes nothing) when the conditions do not hold.
+    template <int LV> __device__ __forceinline__ bool rate1_sure(int plane, const LaneConst &lc, uint64_t &xs)
+    {
+        constexpr int C = 1 << (LV - 3);
+        T mn = fabs_t(R[C]);
+#pragma unroll
+        for (int j = 1; j < C; j++) mn = fmin_t(mn, fabs_t(R[C + j]));
+        mn = fmin_t(mn, partner8<8>(mn));
+        mn = fmin_t(mn, partner8<4>(mn));
+        mn = fmin_t(mn, partner8<2>(mn));
+        T ae;
+        const bool big = sure_exponent(mn, ae);
+        const T DELTA = (T)0.125;
+        const T pm = st.pm;
+        const T next = bperm_f(pm, lc.lane + 8);
+        const T last = lane_value(pm, 8 * (LMAX - 1));
+        const bool ok = big && fabs_t(pm) < (T)4000 && pm + ((T)2 - ae) + DELTA < last + (T)1 && (lc.p == LMAX - 1 || pm - next > DELTA);
+        PROF_COUNT(24 + 2 * (LV - 3));
+#ifdef POLAR_SCL_PROFILE
+        if (LV == 3) {  // why not: smallest LLR too small (32), metric out of range (33), another extension could survive (34), order (35)
+            const bool dead = LMAX < 8 && lc.p >= LMAX;
+            if (__ballot(big || dead) != ~0ull) PROF_COUNT(32);
+            else if (__ballot(fabs_t(pm) < (T)4000 || dead) != ~0ull) PROF_COUNT(33);
+            else if (__ballot(pm + ((T)2 - ae) + DELTA < last + (T)1 || dead) != ~0ull) PROF_COUNT(34);
+            else if (__ballot(ok || dead) != ~0ull) PROF_COUNT(35);
+        }
+#endif
+        if (__ballot(ok || (LMAX < 8 && lc.p >= LMAX)) != ~0ull) return false;
+        PROF_COUNT(25 + 2 * (LV - 3));
+        T acc = pm;
+#pragma unroll 8
+        for (int i = 0; i < (1 << LV); i++) acc += (T)1;
+        st.pm = acc;
+        uint64_t x = 0;
+#pragma unroll
+        for (int j = 0; j < C; j++) x |= (uint64_t)(R[C + j] < (T)0 ? 1u : 0u) << j;
+        xs = x;
+        (void)plane;
+        return true;
+    }
+    // 1 = all frozen, 2 = all information, 0 = mixed, for the node `idx` of level LV (16, 32 or 64 leaves); wave-uniform
+    template <int LV> static __device__ __forceinline__ int node_class(uint32_t maskv, uint32_t idx)
+    {
+        uint32_t lo, hi;
+        if constexpr (LV == 4) {
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)maskv, (int)(idx >> 1));
+            lo = hi = (w >> (16 * (idx & 1))) & 0xFFFFu;
+            hi |= 0xFFFF0000u;
+        } else if constexpr (LV == 5) {
+            lo = hi = (uint32_t)__builtin_amdgcn_readlane((int)maskv, (int)idx);
+        } else {
+            const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)maskv, (int)(2 * idx));
+            const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)maskv, (int)(2 * idx + 1));
+            lo = w0 | w1;
+            hi = w0 & w1;
+        }
+        return lo == 0u ? 1 : hi == 0xFFFFFFFFu ? 2 : 0;
+    }
+
     // A node of P leaves inside the 8-leaf subtree; v replicated with period P over the path's lanes.
     template <int P, uint32_t LIVE = 0u>
     __device__ __forceinline__ uint32_t sub(T v, uint32_t mask, const LaneConst &lc, uint32_t *surv)
@@ -625,7 +767,11 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
             case 0xF8u: return sub_s<8, 0xF8u>(v, lc, surv);
             case 0xFCu: return sub_s<8, 0xFCu>(v, lc, surv);
             case 0xFEu: return sub_s<8, 0xFEu>(v, lc, surv);
-            case 0xFFu: return sub_s<8, 0xFFu>(v, lc, surv);
+            case 0xFFu: {
+                uint64_t xs;
+                if (POLAR_SCL_SURE_TOP >= 3 && rate1_sure<3>(0, lc, xs)) return (uint32_t)xs;
+                return sub_s<8, 0xFFu>(v, lc, surv);
+            }
             default: break;
             }
         }
@@ -655,6 +801,22 @@ __device__ __forceinline__ void scl_node(SclReg<NLOG, LMAX, T> &d, uint32_t mask
                 d.st.ownP = SclReg<NLOG, LMAX, T>::own_set(d.st.ownP, 3, (uint32_t)lc.p);
             }
         } else {
+            if constexpr (LEV - 1 <= 6 && (LEV - 1 <= POLAR_SCL_FROZEN_TOP || LEV - 1 <= POLAR_SCL_SURE_TOP)) {
+                const int cls = SclReg<NLOG, LMAX, T>::template node_class<LEV - 1>(maskv, cidx);
+                if (LEV - 1 <= POLAR_SCL_FROZEN_TOP && cls == 1) {
+                    d.template frozen_subtree<LEV - 1>((int)h, lc);
+                    PROF_ADD(12);
+                    continue;
+                }
+                if (LEV - 1 <= POLAR_SCL_SURE_TOP && cls == 2 && __builtin_amdgcn_readfirstlane(d.Lcur) == LMAX) {
+                    uint64_t xs;
+                    if (d.template rate1_sure<LEV - 1>((int)h, lc, xs)) {
+                        d.template put_sums<LEV - 1>((int)h, xs, lc);
+                        PROF_ADD(20);
+                        continue;
+                    }
+                }
+            }
             scl_node<LEV - 1, NLOG, LMAX, T>(d, maskv, chan_lane, cidx, (int)h, lc, surv PROF_PASS);
         }
     }
@@ -671,7 +833,8 @@ template <int NLOG, int LMAX, typename T>
 __global__ void __launch_bounds__(64, sizeof(T) == 4 ? 4 : (NLOG == 8 || NLOG == POLAR_SCL64_TWO) ? 2 : 3)
 scl_reg_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, const uint16_t *__restrict__ Asl8,
                const uint32_t *__restrict__ crcS, const uint32_t *__restrict__ truth, uint32_t *__restrict__ info_hat, int64_t B, int K,
-               int Kw, void *__restrict__ slab, double *__restrict__ pm_out, uint32_t *__restrict__ u_hat_all)
+               int Kw, void *__restrict__ slab, double *__restrict__ pm_out, uint32_t *__restrict__ u_hat_all, uint32_t slot_words,
+               uint32_t *__restrict__ fault)
 {
     // exchange records of the pruning step (6 words per lane in fp32, 10 in fp64, word-major); its first words double as the
     // survivor table of the general leaf, and the whole area as the staging buffer of the output stage (8 paths x 8 lanes x
@@ -720,16 +883,19 @@ scl_reg_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, co
     SclReg<NLOG, LMAX, T> d;
     d.my_lane = lc.lane;
     d.lv_lds = lvl_s;
-    // The level in global memory (N = 1024) lives in one of SCL_SLAB_SLOTS slabs, claimed here and given back at the end:
-    // the slabs in use are as many as there are resident workgroups, however long the grid is.  slab[0 .. 256) is the
-    // bitmap of claimed slabs (cleared before the launch); there are at least twice as many slabs as resident workgroups,
-    // so the search below always ends.
+    // The level in global memory (N = 1024) lives in one of the launch's slabs (a power of two, at least twice the
+    // workgroups that can be resident: slot_words = slabs / 32), claimed here and given back at the end: the slabs in use are
+    // as many as there are resident workgroups, however long the grid is.  slab[0 .. SCL_SLAB_SLOTS / 32) is the bitmap of
+    // claimed slabs (cleared before the launch).  With that many slabs the search ends within one sweep; a search that has
+    // looked at every word eight times without a claim (a bitmap that was not cleared, a grid beyond what the host sized)
+    // gives up: the workgroup reports through *fault and decodes nothing, instead of spinning for ever.
     uint32_t slab_word = 0, slab_bit = 0;
     if constexpr (St::GLOBAL_VALUES > 0) {
         uint32_t *bm = reinterpret_cast<uint32_t *>(slab);
         if (lc.lane == 0) {
-            uint32_t w = (blockIdx.x * 5u) & (SCL_SLAB_SLOTS / 32 - 1);
-            for (;;) {
+            uint32_t w = (blockIdx.x * 5u) & (slot_words - 1u);
+            xchg[1] = 0xFFFFFFFFu;
+            for (uint32_t tries = 0; tries < 8u * slot_words; tries++) {
                 const uint32_t cur = __hip_atomic_load(bm + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (cur != 0xFFFFFFFFu) {
                     const uint32_t b = (uint32_t)__ffs((int)~cur) - 1u;
@@ -739,14 +905,16 @@ scl_reg_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, co
                         break;
                     }
                 } else {
-                    w = (w + 1u) & (SCL_SLAB_SLOTS / 32 - 1);
+                    w = (w + 1u) & (slot_words - 1u);
                 }
             }
+            if (xchg[1] == 0xFFFFFFFFu) __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         wave_sync();
         slab_word = (uint32_t)__builtin_amdgcn_readfirstlane((int)xchg[0]);
         slab_bit = (uint32_t)__builtin_amdgcn_readfirstlane((int)xchg[1]);
         wave_sync();
+        if (slab_bit == 0xFFFFFFFFu) return;  // wave-uniform
         d.lv_glb = reinterpret_cast<T *>(reinterpret_cast<char *>(slab) + SCL_SLAB_SLOTS / 8) + (size_t)(slab_word * 32u + slab_bit) * St::GLOBAL_VALUES;
     } else {
         d.lv_glb = reinterpret_cast<T *>(slab);
@@ -809,7 +977,24 @@ scl_reg_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, co
                 row[wi] = act ? word : 0u;
             }
         }
-        if (info_hat) {
+        if (POLAR_SCL_BEST_GATHER && info_hat && !crcS && !truth) {
+            // plain decoding: only the best path's information bits leave, and all 64 lanes gather them
+            uint32_t *dst = info_hat + f * Kw;
+            const uint64_t bm = __ballot(act && rank == 0);
+            const uint32_t *best = stage + ((__ffsll((unsigned long long)bm) - 1) >> 3) * 32;
+            uint32_t wmine = 0u;
+            pack_bits_group<64>(
+                K, lc.lane, 0,
+                [&](int k) {
+                    const uint32_t a = ASL_LDS ? asl_s[k] : Asl8[k];  // (lane-in-path << 7) | bit
+                    return ((best[(a >> 7) * 4 + ((a >> 5) & 3u)] >> (a & 31u)) & 1u) != 0u;
+                },
+                [&](int wi, uint32_t v) {
+                    if (wi == lc.lane) wmine = v;
+                });
+            if (lc.lane < Kw) dst[lc.lane] = wmine;
+            if (K == 0 && lc.lane == 0) dst[0] = 0u;
+        } else if (info_hat) {
             uint32_t *dst = info_hat + f * Kw;
             const uint32_t *mine = stage + lc.p * 32;
             uint32_t wout[4] = {0u, 0u, 0u, 0u};
@@ -880,7 +1065,7 @@ scl_reg_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, co
 #ifdef POLAR_SCL_PROFILE
 extern "C" __attribute__((visibility("default"))) int polar_debug_scl_profile(unsigned long long *out, int clear)
 {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scl_prof), sizeof(unsigned long long) * 24) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scl_prof), sizeof(unsigned long long) * 40) != hipSuccess) return -1;
     if (clear) {
         unsigned long long z[64] = {};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_scl_prof), z, sizeof(z)) != hipSuccess) return -1;
@@ -918,21 +1103,28 @@ static int launch_scl_reg_t(polar_code *c, const void *llr, uint32_t *info_hat, 
     int rounds = 32;  // workgroups per resident slot: 14.9 / 16.2 / 16.8 / 17.25 M frames/s at (1024,512), L = 8, fp32, with 1 / 4 / 8 / 32
     if (const char *e = polar_switch("POLAR_SCL_ROUNDS")) rounds = std::max(1, atoi(e));
     int64_t grid = std::min<int64_t>(B, (int64_t)ctx->num_cus * occ * rounds);
-    // the slabs of the levels that live in global memory (fp32, N = 1024: 16 KB each) behind the bitmap of claimed ones
+    // The slabs of the levels that live in global memory (fp32, N = 1024: 16 KB each) behind the bitmap of claimed ones: a
+    // power of two, at least twice the workgroups that can be resident at once (the smaller of grid and what the part
+    // holds), at most SCL_SLAB_SLOTS; a part that could hold more than half of that gets a grid of that many workgroups.
     int rc;
-    if (St::GLOBAL_VALUES > 0 && (int64_t)ctx->num_cus * occ * 2 > SCL_SLAB_SLOTS) {
-        polar_set_error("register list decoder: %d resident workgroups need more than %d slabs", ctx->num_cus * occ, SCL_SLAB_SLOTS);
-        return POLAR_EUNSUPPORTED;
+    int64_t resident = std::min<int64_t>(grid, (int64_t)ctx->num_cus * occ);
+    if (St::GLOBAL_VALUES > 0 && resident * 2 > SCL_SLAB_SLOTS) {
+        grid = std::min<int64_t>(grid, SCL_SLAB_SLOTS / 2);
+        resident = grid;
     }
-    const size_t slab_bytes = St::GLOBAL_VALUES > 0 ? SCL_SLAB_SLOTS / 8 + (size_t)SCL_SLAB_SLOTS * St::GLOBAL_VALUES * sizeof(T) : 4;
+    uint32_t slots = 32;
+    while ((int64_t)slots < 2 * resident) slots *= 2;
+    if (polar_fault_at("scl_slab")) slots = 32, grid = std::min<int64_t>(B, 4096);  // fewer slabs than resident workgroups
+    const size_t slab_bytes = St::GLOBAL_VALUES > 0 ? SCL_SLAB_SLOTS / 8 + (size_t)slots * St::GLOBAL_VALUES * sizeof(T) : 4;
     if ((rc = ctx->scl_slab.reserve(slab_bytes))) return rc;
     if (St::GLOBAL_VALUES > 0) HIP_TRY(hipMemsetAsync(ctx->scl_slab.p, 0, SCL_SLAB_SLOTS / 8, ctx->stream));
     LaunchTimer tm(ctx);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), pad, ctx->stream, (const T *)llr, (const uint32_t *)c->d_maskw,
                        (const uint16_t *)c->d_Asl8, crc ? (const uint32_t *)c->d_crcS : nullptr, truth, info_hat, B, c->K, c->Kw,
-                       (void *)ctx->scl_slab.p, pm, u_hat_all);
+                       (void *)ctx->scl_slab.p, pm, u_hat_all, slots / 32u, ctx->fault_dev);
     HIP_TRY(hipGetLastError());
     float ms = tm.stop();
+    if (ctx->timing && (rc = polar_ctx_check_fault(ctx))) return rc;  // the timer has waited for the kernel
     if (sizeof(T) == 4) snprintf(c->last.kernel, sizeof(c->last.kernel), "scl_reg_kernel<%d>/L%d", NLOG, LMAX);
     else snprintf(c->last.kernel, sizeof(c->last.kernel), "scl_reg_kernel<%d,double>/L%d", NLOG, LMAX);
     c->last.lanes_per_frame = 64;
@@ -949,8 +1141,10 @@ static int launch_scl_reg_l(polar_code *c, const void *llr, uint32_t *info_hat, 
 {
     switch (L) {
     case 8: return launch_scl_reg_t<NLOG, 8, T>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
+#ifndef POLAR_SCL_DEV_ONE  // development builds compile one instantiation (N = 1024, L = 8, fp32) in seconds
     case 4: return launch_scl_reg_t<NLOG, 4, T>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
     case 2: return launch_scl_reg_t<NLOG, 2, T>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
+#endif
     default: polar_set_error("register SCL kernel: list size must be 2, 4 or 8"); return POLAR_EUNSUPPORTED;
     }
 }
@@ -960,10 +1154,12 @@ static int launch_scl_reg_n(polar_code *c, const void *llr, uint32_t *info_hat, 
                             const uint32_t *truth, int L)
 {
     switch (c->n) {
+#ifndef POLAR_SCL_DEV_ONE
     case 6: return launch_scl_reg_l<6, T>(c, llr, info_hat, pm, u_hat_all, B, crc, truth, L);
     case 7: return launch_scl_reg_l<7, T>(c, llr, info_hat, pm, u_hat_all, B, crc, truth, L);
     case 8: return launch_scl_reg_l<8, T>(c, llr, info_hat, pm, u_hat_all, B, crc, truth, L);
     case 9: return launch_scl_reg_l<9, T>(c, llr, info_hat, pm, u_hat_all, B, crc, truth, L);
+#endif
     case 10: return launch_scl_reg_l<10, T>(c, llr, info_hat, pm, u_hat_all, B, crc, truth, L);
     default: polar_set_error("register SCL kernel: unsupported length"); return POLAR_EUNSUPPORTED;
     }
@@ -974,5 +1170,9 @@ int launch_scl_reg(polar_code *c, const void *llr, int dtype, uint32_t *info_hat
 {
     if (B == 0) return POLAR_OK;
     if (dtype == POLAR_F32) return launch_scl_reg_n<float>(c, llr, info_hat, pm, u_hat_all, B, crc, truth, L);
+#ifdef POLAR_SCL_DEV_ONE
+    return POLAR_EUNSUPPORTED;
+#else
     return launch_scl_reg_n<double>(c, llr, info_hat, pm, u_hat_all, B, crc, truth, L);
+#endif
 }

@@ -67,17 +67,30 @@ extern "C" int polar_ctx_create(int device, polar_ctx **out)
     polar_ctx *c = new (std::nothrow) polar_ctx();
     if (!c) return POLAR_ENOMEM;
     c->device = device;
+    // every failure below hands what exists so far to polar_ctx_destroy (which skips what was never made)
     hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
-    c->num_cus = prop.multiProcessorCount;
-    HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess) {
+        c->num_cus = prop.multiProcessorCount;
+        e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    }
     c->stream = c->own_stream;
-    HIP_TRY(hipEventCreate(&c->ev0));
-    HIP_TRY(hipEventCreate(&c->ev1));
-    HIP_TRY(hipStreamCreateWithFlags(&c->gen_stream, hipStreamNonBlocking));
-    for (int i = 0; i < 2; i++) {
-        HIP_TRY(hipEventCreateWithFlags(&c->gen_done[i], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&c->dec_done[i], hipEventDisableTiming));
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = polar_fault_at("ctx_create") ? hipErrorOutOfMemory : hipStreamCreateWithFlags(&c->gen_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->fault_host, 64, hipHostMallocMapped);
+    if (e == hipSuccess) {
+        *c->fault_host = 0u;
+        e = hipHostGetDevicePointer((void **)&c->fault_dev, c->fault_host, 0);
+    }
+    for (int i = 0; i < 2 && e == hipSuccess; i++) {
+        e = hipEventCreateWithFlags(&c->gen_done[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->dec_done[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        polar_set_error("polar_ctx_create: %s", hipGetErrorString(e));
+        (void)polar_ctx_destroy(c);
+        return POLAR_EHIP;
     }
     *out = c;
     return POLAR_OK;
@@ -87,20 +100,24 @@ extern "C" int polar_ctx_destroy(polar_ctx *c)
 {
     if (!c) return POLAR_OK;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->in_bytes, &c->out_bytes, &c->in_words, &c->out_words, &c->llr_buf,   &c->aux_buf,  &c->aux2_buf,
                       &c->pm_buf,   &c->counters,  &c->mc_info,  &c->mc_hat,    &c->flip_rows, &c->flip_ctr, &c->flip_small,
                       &c->mc_llr2,  &c->mc_info2,  &c->scl_slab,  &c->flip_pairs};
     for (DevBuf *b : bufs) b->release();
-    (void)hipEventDestroy(c->ev0);
-    (void)hipEventDestroy(c->ev1);
-    (void)hipStreamSynchronize(c->gen_stream);
-    (void)hipStreamDestroy(c->gen_stream);
-    for (int i = 0; i < 2; i++) {
-        (void)hipEventDestroy(c->gen_done[i]);
-        (void)hipEventDestroy(c->dec_done[i]);
+    // a context whose creation failed half-way holds only some of these
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->gen_stream) {
+        (void)hipStreamSynchronize(c->gen_stream);
+        (void)hipStreamDestroy(c->gen_stream);
     }
-    (void)hipStreamDestroy(c->own_stream);
+    for (int i = 0; i < 2; i++) {
+        if (c->gen_done[i]) (void)hipEventDestroy(c->gen_done[i]);
+        if (c->dec_done[i]) (void)hipEventDestroy(c->dec_done[i]);
+    }
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->fault_host) (void)hipHostFree(c->fault_host);
     delete c;
     return POLAR_OK;
 }
@@ -111,11 +128,18 @@ extern "C" int polar_ctx_set_stream(polar_ctx *c, void *s)
     c->stream = s ? (hipStream_t)s : c->own_stream;
     return POLAR_OK;
 }
+int polar_ctx_check_fault(polar_ctx *ctx)
+{
+    if (!ctx->fault_host || *(volatile uint32_t *)ctx->fault_host == 0u) return POLAR_OK;
+    *(volatile uint32_t *)ctx->fault_host = 0u;
+    polar_set_error("a decoder kernel gave up: the register list decoder found no free slab for its wide levels (results of the call are incomplete)");
+    return POLAR_EHIP;
+}
 extern "C" int polar_ctx_sync(polar_ctx *c)
 {
     ARG_TRY(c != nullptr, "ctx is NULL");
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return POLAR_OK;
+    return polar_ctx_check_fault(c);
 }
 extern "C" int polar_ctx_num_cus(polar_ctx *c) { return c ? c->num_cus : 0; }
 extern "C" int polar_ctx_enable_timing(polar_ctx *c, int on)
@@ -528,7 +552,10 @@ static int sc_common(polar_code *c, const void *llr, int dtype, void *info_hat, 
         if (space == POLAR_HOST && dec_llr)
             HIP_TRY(hipMemcpyAsync((char *)dec_llr + b0 * c->N * es, ddec, nb * c->N * es, hipMemcpyDeviceToHost, ctx->stream));
     }
-    if (space == POLAR_HOST) HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (space == POLAR_HOST) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (int frc = polar_ctx_check_fault(ctx)) return frc;
+    }
     return POLAR_OK;
 }
 
@@ -619,7 +646,10 @@ static int scl_common(polar_code *c, const void *llr, int dtype, int L, void *in
         }
         if (space == POLAR_HOST && pm) HIP_TRY(hipMemcpyAsync(pm + b0 * L, dpm, nb * L * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     }
-    if (space == POLAR_HOST) HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (space == POLAR_HOST) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (int frc = polar_ctx_check_fault(ctx)) return frc;
+    }
     return POLAR_OK;
 }
 
@@ -814,7 +844,10 @@ static int pbf_common(polar_code *c, const void *llr, int dtype, int max_level, 
             if (crc_ok) HIP_TRY(hipMemcpyAsync(crc_ok + b0, d_ok, nb, hipMemcpyDeviceToHost, ctx->stream));
         }
     }
-    if (space == POLAR_HOST) HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (space == POLAR_HOST) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (int frc = polar_ctx_check_fault(ctx)) return frc;
+    }
     return POLAR_OK;
 }
 
@@ -1059,39 +1092,55 @@ extern "C" int polar_mc_run(polar_code *c, int decoder, int L, int dtype, int fl
     // the generator must not overtake work the caller queued earlier on the context's stream
     HIP_TRY(hipEventRecord(ctx->dec_done[1], main_stream));
     HIP_TRY(hipStreamWaitEvent(ctx->gen_stream, ctx->dec_done[1], 0));
-    int64_t idx = 0;
     struct Overlap {  // decoders size their grids for a GPU they share with the generator while this loop runs
         polar_ctx *c;
         explicit Overlap(polar_ctx *x) : c(x) { c->overlapped = true; }
         ~Overlap() { c->overlapped = false; }
     } overlap(ctx);
-    for (int64_t f0 = 0; f0 < nframes; f0 += chunk, idx++) {
-        const int64_t nb = std::min(chunk, nframes - f0);
-        const int b = (int)(idx & 1);
-        // generate into buffer b once the decode that last read it (chunk idx-2) is done
-        if (idx >= 2) HIP_TRY(hipStreamWaitEvent(ctx->gen_stream, ctx->dec_done[b], 0));
-        ctx->stream = ctx->gen_stream;
-        rc = launch_gen_frames(c, info_b[b], llr_b[b], dtype, N0, seed, frame0 + f0, nb, crc);
-        ctx->stream = main_stream;
-        if (rc) return rc;
-        HIP_TRY(hipEventRecord(ctx->gen_done[b], ctx->gen_stream));
-        HIP_TRY(hipStreamWaitEvent(main_stream, ctx->gen_done[b], 0));
-        if (decoder == POLAR_DEC_SC) {
-            if ((rc = sc_decode_count(c, llr_b[b], dtype, info_b[b], nullptr, nb, flags, dcnt, c->K))) return rc;
+    // the two-stream loop; on an error it returns at once and the caller below drains both streams
+    auto pipeline = [&]() -> int {
+        int64_t idx = 0;
+        for (int64_t f0 = 0; f0 < nframes; f0 += chunk, idx++) {
+            const int64_t nb = std::min(chunk, nframes - f0);
+            const int b = (int)(idx & 1);
+            // generate into buffer b once the decode that last read it (chunk idx-2) is done
+            if (idx >= 2) HIP_TRY(hipStreamWaitEvent(ctx->gen_stream, ctx->dec_done[b], 0));
+            ctx->stream = ctx->gen_stream;
+            int r = launch_gen_frames(c, info_b[b], llr_b[b], dtype, N0, seed, frame0 + f0, nb, crc);
+            ctx->stream = main_stream;
+            if (r) return r;
+            HIP_TRY(hipEventRecord(ctx->gen_done[b], ctx->gen_stream));
+            HIP_TRY(hipStreamWaitEvent(main_stream, ctx->gen_done[b], 0));
+            if (idx == 1 && polar_fault_at("mc_run")) {
+                polar_set_error("polar_mc_run: injected failure in chunk %lld", (long long)idx);
+                return POLAR_EHIP;
+            }
+            if (decoder == POLAR_DEC_SC) {
+                if ((r = sc_decode_count(c, llr_b[b], dtype, info_b[b], nullptr, nb, flags, dcnt, c->K))) return r;
+                HIP_TRY(hipEventRecord(ctx->dec_done[b], main_stream));
+                continue;
+            } else if (decoder == POLAR_DEC_PBF)
+                r = pbf_device(c, llr_b[b], dtype, L, ctx->mc_hat.as<uint32_t>(), nullptr, nullptr, nullptr, nb);
+            else
+                r = launch_scl_decode(c, llr_b[b], dtype, L, ctx->mc_hat.as<uint32_t>(), nullptr, nullptr, nb, crc,
+                                      (flags & POLAR_GENIE) ? info_b[b] : nullptr);
+            if (r) return r;
+            if ((r = launch_count_errors(c, info_b[b], ctx->mc_hat.as<uint32_t>(), nb, dcnt, crc ? c->K - c->crc_w : c->K))) return r;
             HIP_TRY(hipEventRecord(ctx->dec_done[b], main_stream));
-            continue;
-        } else if (decoder == POLAR_DEC_PBF)
-            rc = pbf_device(c, llr_b[b], dtype, L, ctx->mc_hat.as<uint32_t>(), nullptr, nullptr, nullptr, nb);
-        else
-            rc = launch_scl_decode(c, llr_b[b], dtype, L, ctx->mc_hat.as<uint32_t>(), nullptr, nullptr, nb, crc,
-                                   (flags & POLAR_GENIE) ? info_b[b] : nullptr);
-        if (rc) return rc;
-        if ((rc = launch_count_errors(c, info_b[b], ctx->mc_hat.as<uint32_t>(), nb, dcnt, crc ? c->K - c->crc_w : c->K))) return rc;
-        HIP_TRY(hipEventRecord(ctx->dec_done[b], main_stream));
+        }
+        return POLAR_OK;
+    };
+    if ((rc = pipeline())) {
+        // nothing stays in flight: the generator may still be writing a buffer that the next call hands out again
+        ctx->stream = main_stream;
+        (void)hipStreamSynchronize(ctx->gen_stream);
+        (void)hipStreamSynchronize(main_stream);
+        return rc;
     }
     uint64_t h[3];
     HIP_TRY(hipMemcpyAsync(h, dcnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if ((rc = polar_ctx_check_fault(ctx))) return rc;
     for (int i = 0; i < 3; i++) counters[i] += h[i];
     return POLAR_OK;
 }

@@ -1,6 +1,7 @@
 // Internal declarations shared by the translation units of libpolar_hip.so.
 #pragma once
 #include <stdlib.h>
+#include <string.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -55,7 +56,12 @@ struct polar_ctx {
     DevBuf mc_llr2, mc_info2;  // second buffers of the Monte-Carlo pipeline (mc_llr2 also of the host-space LLR feed)
     DevBuf flip_rows, flip_ctr, flip_small;  // failing-frame list, {work counter, row count}, per-frame side outputs
     DevBuf flip_pairs;                       // two-flip search: frames, best pairs and ranked first flips of the frames it works on
+    // one word of page-locked host memory that kernels can write (fault_dev is its device address): a kernel that gives up
+    // (the slab search of the register list decoder) says so here, and the next synchronising call returns POLAR_EHIP
+    uint32_t *fault_host = nullptr, *fault_dev = nullptr;
 };
+// after the context's stream was synchronised: POLAR_EHIP (and the word cleared) if a kernel reported a fault
+int polar_ctx_check_fault(polar_ctx *ctx);
 
 struct polar_code {
     polar_ctx *ctx = nullptr;
@@ -151,6 +157,14 @@ inline const char *polar_switch(const char *name)
     const char *on = getenv("POLAR_EXPERIMENT");
     if (!on || on[0] != '1') return nullptr;
     return getenv(name);
+}
+
+// Failure injection for the tests of the error paths (POLAR_FAULT_AT=<site>, honoured like every switch only with
+// POLAR_EXPERIMENT=1): the named site behaves as if its runtime call had failed.
+inline bool polar_fault_at(const char *site)
+{
+    const char *e = polar_switch("POLAR_FAULT_AT");
+    return e && strcmp(e, site) == 0;
 }
 
 struct LaunchTimer {
