@@ -469,7 +469,7 @@ int launch_scl_decode(polar_code *c, const void *llr, int dtype, int L, uint32_t
         return POLAR_EUNSUPPORTED;
     }
     if (scl_reg_supported(c, dtype, L, pm, u_hat_all)) return launch_scl_reg(c, llr, dtype, info_hat, pm, u_hat_all, B, crc, truth, L);
-    if (scl_wide_supported(c, dtype, L, pm, u_hat_all)) return launch_scl_wide(c, llr, info_hat, B, L, crc, truth);
+    if (scl_wide_supported(c, dtype, L, pm, u_hat_all)) return launch_scl_wide(c, llr, dtype, info_hat, pm, u_hat_all, B, L, crc, truth);
     if (dtype == POLAR_F32) return launch_scl_l<float>(c, llr, L, info_hat, pm, u_hat_all, B, crc, truth);
     return launch_scl_l<double>(c, llr, L, info_hat, pm, u_hat_all, B, crc, truth);
 }

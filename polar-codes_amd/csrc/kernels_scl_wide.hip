@@ -1,6 +1,7 @@
 // Register-resident list decoder for long lists: up to L = 32 paths (L = 16 leaves half of the positions empty),
-// N = 64 .. 1024, fp32, information bits of the best path (or of the first path in metric order that passes the CRC /
-// equals the transmitted word): one wavefront per frame, two lanes per path.
+// N = 64 .. 1024, fp32 or fp64, information bits of the best path (or of the first path in metric order that passes the
+// CRC / equals the transmitted word) and, when asked for, the whole list in metric order with its metrics: one wavefront
+// per frame, two lanes per path.
 //
 // Lane 2p + h belongs to list position p.  Element k of every tree level of a path lives in the lane with h = k & 1,
 // at index k >> 1, so the partners (k, k + half) of every f and g down to level 2 sit in one lane and are plain
@@ -21,7 +22,9 @@
 // equal metrics are rare; they show as a missing or doubly claimed rank and send the wavefront through a second
 // count that adds the equal keys standing earlier in the candidate order -- the stable descending sort of the
 // reference's polarSCLFork (cn/polarCode.py:969-1005).  Rank r < L becomes list position r.
-// Metric, arithmetic and order of operations are those of scl_decode_kernel<float, L>: the two give the same bits.
+// Metric, arithmetic and order of operations are those of scl_decode_kernel<T, L>: the two give the same bits, and in
+// fp64 (the reference's arithmetic: the metric as cn/polarCode.py:982-988 writes it, operation by operation) the same
+// metrics.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -33,12 +36,23 @@
 namespace {
 
 __device__ __forceinline__ float wb_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(lane << 2, __float_as_int(v))); }
+__device__ __forceinline__ double wb_f(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(lane << 2, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(lane << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ uint32_t wb_u(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute(lane << 2, (int)v); }
 __device__ __forceinline__ uint64_t wb_u64(uint64_t v, int lane)
 {
     return ((uint64_t)wb_u((uint32_t)(v >> 32), lane) << 32) | wb_u((uint32_t)v, lane);
 }
-__device__ __forceinline__ float swap2(float v) { return dpp_mov<0xB1>(v); }  // quad_perm:[1,0,3,2]: the other lane of my path
+template <typename T> __device__ __forceinline__ T swap2(T v) { return dpp_mov<0xB1>(v); }  // quad_perm:[1,0,3,2]: the other lane of my path
+__device__ __forceinline__ float lane_of(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+__device__ __forceinline__ double lane_of(double v, int src)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
 
 // fp32 branch metric of deciding u at decision LLR v, as in the other list kernels (overflow-free; -inf only where the
 // reference overflows)
@@ -50,18 +64,33 @@ __device__ __forceinline__ float wide_metric(float v, uint32_t u)
     const float r = 1.0f - (m + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(e))));
     return e >= 1024.0f ? -INFINITY : r;
 }
-// integer with the order of the float (no NaN and no -0 occur among metrics)
+// fp64: the reference's expression, operation by operation (cn/polarCode.py:982-988 and :2066-2067)
+__device__ __forceinline__ double wide_metric(double v, uint32_t u)
+{
+    const double Li = v / 0.693147180559945309417232121458;
+    const double e = u ? Li : -Li;
+    return 1.0 - log2(1.0 + exp2(e));
+}
+// integer with the order of the metric (no NaN and no -0 occur among metrics)
 __device__ __forceinline__ uint32_t order_key(float v)
 {
     const uint32_t x = __float_as_uint(v);
     return x ^ ((uint32_t)((int32_t)x >> 31) | 0x80000000u);
 }
+__device__ __forceinline__ uint64_t order_key(double v)
+{
+    const uint64_t x = (uint64_t)__double_as_longlong(v);
+    return x ^ ((uint64_t)((int64_t)x >> 63) | 0x8000000000000000ull);
+}
+template <typename T> struct KeyOf { using type = uint32_t; };
+template <> struct KeyOf<double> { using type = uint64_t; };
 
-template <int NLOG> struct WideStore {
+template <int NLOG, typename T> struct WideStore {
     static constexpr int TOP = NLOG - 1;                         // widest stored level
-    static constexpr int LDS_LEVEL = NLOG >= 8 ? 6 : 99;         // from N = 256 on level 6 (32 values per lane) lives in LDS, lane-major
-    static constexpr int LDS_VALUES = NLOG >= 8 ? 32 * 64 : 1;   // floats per wavefront
-    static constexpr int REG_TOP = NLOG >= 8 ? 5 : (TOP < 6 ? TOP : 6);  // levels 1 .. REG_TOP in registers
+    static constexpr bool SPLIT = NLOG >= (sizeof(T) == 4 ? 8 : 7);  // from N = 256 on (fp64: 128) level 6 (32 values per lane) lives in LDS, lane-major
+    static constexpr int LDS_LEVEL = SPLIT ? 6 : 99;
+    static constexpr int LDS_VALUES = SPLIT ? 32 * 64 : 1;       // values per wavefront
+    static constexpr int REG_TOP = SPLIT ? 5 : (TOP < 6 ? TOP : 6);  // levels 1 .. REG_TOP in registers
     static constexpr int REG_VALUES = 1 << REG_TOP;              // level l: 2^(l-1) values at offset 2^(l-1)
     static constexpr int mem_off(int l)                          // first slab row of level l (rows of 64 lanes)
     {
@@ -72,21 +101,22 @@ template <int NLOG> struct WideStore {
     static constexpr int MEM_ROWS = TOP >= 7 ? mem_off(TOP + 1) : 0;
 };
 
-template <int NLOG, int LMAX> struct WideDec {
-    using St = WideStore<NLOG>;
+template <int NLOG, int LMAX, typename T> struct WideDec {
+    using St = WideStore<NLOG, T>;
+    using Key = typename KeyOf<T>::type;
     static constexpr int N = 1 << NLOG;
-    float R[St::REG_VALUES];
-    float *memu;           // the wavefront's slab (wave-uniform)
-    float *lds6u;          // the wavefront's LDS level (wave-uniform)
-    const float *chs;      // the frame's channel LLRs in LDS, [parity][N/2], + my parity's half
+    T R[St::REG_VALUES];
+    T *memu;               // the wavefront's slab (wave-uniform)
+    T *lds6u;              // the wavefront's LDS level (wave-uniform)
+    const T *chs;          // the frame's channel LLRs in LDS, [parity][N/2], + my parity's half
     int lane, p, h;
     // partial sums per plane: a level whose nodes have C bits per lane sits in W[0] at bit offset C for C <= 32, in W[1]
     // for C = 64, in W[2..3] for C = 128, in W[4..7] for C = 256; the root (N / 2 bits per lane) fills Rt from bit 0
     static constexpr int SW = NLOG >= 10 ? 8 : 4;
     uint64_t A[SW], Bp[SW], Rt[SW];
-    float pm;
+    T pm;
     uint32_t oL[2], oP[2];  // owner rows, 5 bits per level: levels 1 .. 6 in word 0, from 7 on in word 1; oL[1] bit 31: see node2
-    float x;                // my element of the enclosing 2-leaf node's LLRs while its first leaf is decided
+    T x;                    // my element of the enclosing 2-leaf node's LLRs while its first leaf is decided
     int Lcur;
 
     template <int LEV> static __device__ __forceinline__ uint32_t own_get(const uint32_t *row)
@@ -107,19 +137,19 @@ template <int NLOG, int LMAX> struct WideDec {
         asm volatile("" : "+v"(v));
         return v;
     }
-    template <int L> __device__ __forceinline__ float ld_own(int j, int lq) const
+    template <int L> __device__ __forceinline__ T ld_own(int j, int lq) const
     {
         if constexpr (L >= 7) return memu[(St::mem_off(L) + j) * 64 + lq];
         else if constexpr (L == St::LDS_LEVEL) return lds6u[j * 64 + lq];
         else return R[(1 << (L - 1)) + j];
     }
-    template <int L> __device__ __forceinline__ float ld_from(int j, int src) const
+    template <int L> __device__ __forceinline__ T ld_from(int j, int src) const
     {
         if constexpr (L >= 7) return memu[(St::mem_off(L) + j) * 64 + src];
         else if constexpr (L == St::LDS_LEVEL) return lds6u[j * 64 + src];
         else return wb_f(R[(1 << (L - 1)) + j], src);
     }
-    template <int L> __device__ __forceinline__ void st_own(int j, float v, int lq)
+    template <int L> __device__ __forceinline__ void st_own(int j, T v, int lq)
     {
         if constexpr (L >= 7) memu[(St::mem_off(L) + j) * 64 + lq] = v;
         else if constexpr (L == St::LDS_LEVEL) lds6u[j * 64 + lq] = v;
@@ -207,11 +237,12 @@ template <int NLOG, int LMAX> struct WideDec {
     {
         constexpr int c = 1 << (LEV - 2);
         constexpr bool MEM = LEV == NLOG || LEV >= 7 || LEV == St::LDS_LEVEL;
-        constexpr int BT = !MEM ? 1 : c < 16 ? c : 16;
+        constexpr int BMAX = sizeof(T) == 4 ? 16 : 8;  // pairs in flight: 32 registers of operands either way
+        constexpr int BT = !MEM ? 1 : c < BMAX ? c : BMAX;
         const int lq = opaque(lane);
 #pragma unroll
         for (int j0 = 0; j0 < c; j0 += BT) {
-            float a[BT], b[BT];
+            T a[BT], b[BT];
 #pragma unroll
             for (int t = 0; t < BT; t++) {
                 if constexpr (LEV == NLOG) {
@@ -232,14 +263,15 @@ template <int NLOG, int LMAX> struct WideDec {
     {
         constexpr int c = 1 << (LEV - 2);
         constexpr bool MEM = LEV == NLOG || LEV >= 7 || LEV == St::LDS_LEVEL;
-        constexpr int BT = MEM ? (c < 16 ? c : 16) : (c < 4 ? c : 4);
+        constexpr int BMAX = sizeof(T) == 4 ? 16 : 8;
+        constexpr int BT = MEM ? (c < BMAX ? c : BMAX) : (c < 4 ? c : 4);
         const int lq = opaque(lane);
         const int srcP = (int)own_get<LEV - 1>(oP) * 2 + h;
         const int srcL = opaque((LEV == NLOG) ? 0 : (int)own_get<(LEV == NLOG ? 1 : LEV)>(oL) * 2 + h);
         const Bits bits = fetch_bits<c>(srcP);
 #pragma unroll
         for (int j0 = 0; j0 < c; j0 += BT) {
-            float a[BT], b[BT];
+            T a[BT], b[BT];
 #pragma unroll
             for (int t = 0; t < BT; t++) {
                 if constexpr (LEV == NLOG) {
@@ -278,7 +310,7 @@ template <int NLOG, int LMAX> struct WideDec {
     // ---- fork / prune -------------------------------------------------------------------------------------------
     // my position becomes the continuation u = b of the path in position par (cpm: every lane's candidate metric);
     // WITH_X: the first leaf of a 2-leaf node, whose LLRs travel with the path
-    template <bool WITH_X> __device__ __forceinline__ void take_over(float cpm, int par, uint32_t b)
+    template <bool WITH_X> __device__ __forceinline__ void take_over(T cpm, int par, uint32_t b)
     {
         const int src = par * 2 + h;
         pm = wb_f(cpm, par * 2 + (int)b);
@@ -291,7 +323,7 @@ template <int NLOG, int LMAX> struct WideDec {
 
     // One leaf; v = its decision LLR (the same in both lanes of a path).  Returns the bit of the path that holds
     // this position afterwards.  keys: 64 words of LDS, inv: 32 words.
-    template <bool WITH_X> __device__ __forceinline__ uint32_t leaf(float v, uint32_t is_info, uint32_t *keys, uint32_t *inv)
+    template <bool WITH_X> __device__ __forceinline__ uint32_t leaf(T v, uint32_t is_info, Key *keys, uint32_t *inv)
     {
         if (!is_info) {
             pm += wide_metric(v, 0u);
@@ -301,19 +333,19 @@ template <int NLOG, int LMAX> struct WideDec {
             // The list is full.  A leaf every path is sure of ends before any metric is evaluated or ranked (sure_exponent in
             // decode_common.h has the argument): the ranking below would give each position its own path's agreeing extension
             // with this very metric, and nothing would move.
-            float ae;
+            T ae;
             const bool big = sure_exponent(v, ae);
-            const float cpm_a = pm + 1.0f;
-            const float next = wb_f(cpm_a, lane + 2);  // the agreeing extension of the next list position
-            const float other = pm + (2.0f - ae);
-            const float last = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cpm_a), 2 * (LMAX - 1)));
+            const T cpm_a = pm + (T)1;
+            const T next = wb_f(cpm_a, lane + 2);  // the agreeing extension of the next list position
+            const T other = pm + ((T)2 - ae);
+            const T last = lane_of(cpm_a, 2 * (LMAX - 1));
             const bool sure = big && other < last && (p == LMAX - 1 || cpm_a > next);
             if (__ballot(sure || (LMAX < 32 && p >= LMAX)) == ~0ull) {
                 pm = cpm_a;
-                return v < 0.0f ? 1u : 0u;
+                return v < (T)0 ? 1u : 0u;
             }
         }
-        const float cpm = pm + wide_metric(v, (uint32_t)h);
+        const T cpm = pm + wide_metric(v, (uint32_t)h);
         if (2 * Lcur <= LMAX) {  // list = originals ++ copies
             const bool is_copy = p >= Lcur && p < 2 * Lcur;
             const int par = is_copy ? p - Lcur : p;
@@ -323,19 +355,28 @@ template <int NLOG, int LMAX> struct WideDec {
             return b;
         }
         const bool alive = LMAX == 32 || p < LMAX;
-        const uint32_t key = alive ? order_key(cpm) : 0u;  // below the key of -inf
+        const Key key = alive ? order_key(cpm) : (Key)0;  // below the key of -inf
         const int mypos = h ? p : 32 + p;                  // copies (u = 1) come first in the candidate order
         keys[mypos] = key;
         if (lane < LMAX) inv[lane] = 0xFFFFFFFFu;
         wave_sync();
         int cnt = 0;
+        if constexpr (sizeof(T) == 4) {
 #pragma unroll
-        for (int i = 0; i < 64; i += 4) {
-            const uint4 k4 = *reinterpret_cast<const uint4 *>(keys + i);
-            cnt += (k4.x > key) ? 1 : 0;
-            cnt += (k4.y > key) ? 1 : 0;
-            cnt += (k4.z > key) ? 1 : 0;
-            cnt += (k4.w > key) ? 1 : 0;
+            for (int i = 0; i < 64; i += 4) {
+                const uint4 k4 = *reinterpret_cast<const uint4 *>(keys + i);
+                cnt += (k4.x > key) ? 1 : 0;
+                cnt += (k4.y > key) ? 1 : 0;
+                cnt += (k4.z > key) ? 1 : 0;
+                cnt += (k4.w > key) ? 1 : 0;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 64; i += 2) {
+                const ulonglong2 k2 = *reinterpret_cast<const ulonglong2 *>(keys + i);
+                cnt += (k2.x > key) ? 1 : 0;
+                cnt += (k2.y > key) ? 1 : 0;
+            }
         }
         if (cnt < LMAX) inv[cnt] = (uint32_t)lane;
         wave_sync();
@@ -350,7 +391,7 @@ template <int NLOG, int LMAX> struct WideDec {
             cnt = 0;
 #pragma unroll 4
             for (int i = 0; i < 64; i++) {
-                const uint32_t k = keys[i];
+                const Key k = keys[i];
                 cnt += (k > key || (k == key && i < mypos)) ? 1 : 0;
             }
             if (cnt < LMAX) inv[cnt] = (uint32_t)lane;
@@ -361,7 +402,7 @@ template <int NLOG, int LMAX> struct WideDec {
         const uint32_t b = win & 1u;
         const int par = (int)(win >> 1);
         if (__ballot(alive && par != p) == 0) {  // nothing moves between positions
-            const float other = swap2(cpm);
+            const T other = swap2(cpm);
             pm = (b == (uint32_t)h) ? cpm : other;
             return b;
         }
@@ -370,22 +411,23 @@ template <int NLOG, int LMAX> struct WideDec {
     }
 
     // A 2-leaf node; xin = my element of its LLRs, m2 = its rate profile.  Returns my element of its partial sums.
-    __device__ __forceinline__ uint32_t node2(float xin, uint32_t m2, uint32_t *keys, uint32_t *inv)
+    __device__ __forceinline__ uint32_t node2(T xin, uint32_t m2, Key *keys, uint32_t *inv)
     {
         x = xin;
-        const float v0 = f_fast(x, swap2(x));
+        const T v0 = f_fast(x, swap2(x));
         const uint32_t u0 = leaf<true>(v0, m2 & 1u, keys, inv);
         oL[1] = (oL[1] & 0x7FFFFFFFu) | (u0 << 31);  // travels with the path through the forks of the second leaf
-        const float t = h ? x : flip_sign(x, u0);
-        const float v1 = t + swap2(t);
+        const T t = h ? x : flip_sign(x, u0);
+        const T v1 = t + swap2(t);
         const uint32_t u1 = leaf<false>(v1, (m2 >> 1) & 1u, keys, inv);
         const uint32_t u0_now = oL[1] >> 31;
         return h ? u1 : (u0_now ^ u1);
     }
 };
 
-template <int LEV, int NLOG, int LMAX>
-__device__ __forceinline__ void wide_node(WideDec<NLOG, LMAX> &d, uint32_t maskv, uint32_t idx, int plane, uint32_t *keys, uint32_t *inv)
+template <int LEV, int NLOG, int LMAX, typename T>
+__device__ __forceinline__ void wide_node(WideDec<NLOG, LMAX, T> &d, uint32_t maskv, uint32_t idx, int plane, typename KeyOf<T>::type *keys,
+                                          uint32_t *inv)
 {
 #pragma nounroll
     for (uint32_t hh = 0; hh < 2; hh++) {
@@ -400,10 +442,10 @@ __device__ __forceinline__ void wide_node(WideDec<NLOG, LMAX> &d, uint32_t maskv
                 d.Bp[0] = (d.Bp[0] & ~(uint64_t)2) | ((uint64_t)xb << 1);
             } else {
                 d.A[0] = (d.A[0] & ~(uint64_t)2) | ((uint64_t)xb << 1);
-                WideDec<NLOG, LMAX>::template own_set<1>(d.oP, (uint32_t)d.p);
+                WideDec<NLOG, LMAX, T>::template own_set<1>(d.oP, (uint32_t)d.p);
             }
         } else {
-            wide_node<LEV - 1, NLOG, LMAX>(d, maskv, cidx, (int)hh, keys, inv);
+            wide_node<LEV - 1, NLOG, LMAX, T>(d, maskv, cidx, (int)hh, keys, inv);
         }
     }
     d.template combine<LEV>(plane);
@@ -419,55 +461,68 @@ __device__ __forceinline__ uint32_t spread16(uint32_t v)
     return v;
 }
 
-template <int NLOG, int LMAX>
-__global__ void __launch_bounds__(64, 3) scl_wide_kernel(const float *__restrict__ llr, const uint32_t *__restrict__ maskw,
-                                                        const uint32_t *__restrict__ Apos, uint32_t *__restrict__ info_hat, int64_t B,
-                                                        int K, int Kw, float *__restrict__ slab, const uint32_t *__restrict__ crcS,
-                                                        const uint32_t *__restrict__ truth)
+// List outputs (pm_out, u_hat_all; either may be NULL) are those of scl_decode_kernel: row f * LMAX + r holds the path of
+// rank r in the stable descending order of the metrics, rows of empty positions keep their index, -inf and zeros.
+template <int NLOG, int LMAX, typename T>
+__global__ void __launch_bounds__(64, sizeof(T) == 4 ? 3 : 2)
+scl_wide_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, const uint32_t *__restrict__ Apos,
+                uint32_t *__restrict__ info_hat, int64_t B, int K, int Kw, T *__restrict__ slab, const uint32_t *__restrict__ crcS,
+                const uint32_t *__restrict__ truth, double *__restrict__ pm_out, uint32_t *__restrict__ u_hat_all)
 {
     constexpr int N = 1 << NLOG;
     constexpr int NW = N / 32;
-    __shared__ __attribute__((aligned(16))) float chan_s[N];  // [parity][N/2]; the output stage reuses it for bit words
-    __shared__ __attribute__((aligned(16))) uint32_t keys[64];
+    using Dec = WideDec<NLOG, LMAX, T>;
+    using Key = typename Dec::Key;
+    __shared__ __attribute__((aligned(16))) T chan_s[N];  // [parity][N/2]; the output stage reuses it for bit words
+    __shared__ __attribute__((aligned(16))) Key keys[64];
     __shared__ uint32_t inv[32];
-    __shared__ float lvl6_s[WideStore<NLOG>::LDS_VALUES];
-    using Dec = WideDec<NLOG, LMAX>;
+    __shared__ T lvl6_s[WideStore<NLOG, T>::LDS_VALUES];
     Dec d;
     d.lane = threadIdx.x;
     d.p = d.lane >> 1;
     d.h = d.lane & 1;
-    d.memu = slab + (size_t)blockIdx.x * (WideStore<NLOG>::MEM_ROWS > 0 ? WideStore<NLOG>::MEM_ROWS : 1) * 64;
+    d.memu = slab + (size_t)blockIdx.x * (WideStore<NLOG, T>::MEM_ROWS > 0 ? WideStore<NLOG, T>::MEM_ROWS : 1) * 64;
     d.chs = chan_s + d.h * (N / 2);
     d.lds6u = lvl6_s;
     const uint32_t maskv = maskw[(d.lane & 31) < NW ? (d.lane & 31) : 0];
 
     for (int64_t f = blockIdx.x; f < B; f += gridDim.x) {
         // channel LLRs of the frame: coalesced 16-byte loads, stored split by parity (element 2j + h at [h][j])
-        const float4 *src = reinterpret_cast<const float4 *>(llr + f * N);
+        if constexpr (sizeof(T) == 4) {
+            const float4 *src = reinterpret_cast<const float4 *>(llr + f * N);
 #pragma unroll
-        for (int t = d.lane; t < N / 4; t += 64) {
-            const float4 v = src[t];
-            *reinterpret_cast<float2 *>(chan_s + 2 * t) = make_float2(v.x, v.z);
-            *reinterpret_cast<float2 *>(chan_s + N / 2 + 2 * t) = make_float2(v.y, v.w);
+            for (int t = d.lane; t < N / 4; t += 64) {
+                const float4 v = src[t];
+                *reinterpret_cast<float2 *>(chan_s + 2 * t) = make_float2(v.x, v.z);
+                *reinterpret_cast<float2 *>(chan_s + N / 2 + 2 * t) = make_float2(v.y, v.w);
+            }
+        } else {
+            const double2 *src = reinterpret_cast<const double2 *>(llr + f * N);
+#pragma unroll
+            for (int t = d.lane; t < N / 2; t += 64) {
+                const double2 v = src[t];
+                chan_s[t] = v.x;
+                chan_s[N / 2 + t] = v.y;
+            }
         }
 #pragma unroll
         for (int i = 0; i < Dec::SW; i++) d.A[i] = d.Bp[i] = d.Rt[i] = 0;
-        d.pm = 0.0f;
+        d.pm = (T)0;
         d.oL[0] = d.oL[1] = d.oP[0] = d.oP[1] = 0u;
-        d.x = 0.0f;
+        d.x = (T)0;
         d.Lcur = 1;
         wave_sync();
-        wide_node<NLOG, NLOG, LMAX>(d, maskv, 0u, 0, keys, inv);
+        wide_node<NLOG, NLOG, LMAX, T>(d, maskv, 0u, 0, keys, inv);
 
         // rank of every path in the stable descending order of the list
         const bool act = d.p < d.Lcur;
-        const uint32_t key = (act && d.h == 0) ? order_key(d.pm) : 0u;
+        const Key key = (act && d.h == 0) ? order_key(d.pm) : (Key)0;
         keys[d.h ? 32 + d.p : d.p] = key;
         wave_sync();
         int rank = 0;
 #pragma unroll 4
         for (int q = 0; q < 32; q++) {
-            const uint32_t k = keys[q];
+            const Key k = keys[q];
             rank += (k > key || (k == key && q < d.p)) ? 1 : 0;
         }
         wave_sync();
@@ -504,90 +559,116 @@ __global__ void __launch_bounds__(64, 3) scl_wide_kernel(const float *__restrict
             const uint32_t pos = Apos[k];
             return ((uw[pos >> 5] >> (pos & 31)) & 1u) != 0u;
         };
-        if (crcS || truth) {
-            // aided choice: the first path in metric order that passes, the best one if none does
-            int sel = -1;
-            for (int r = 0; r < d.Lcur && sel < 0; r++) {
-                path_words((int)inv[r]);
-                bool ok;
-                if (truth) {
-                    const uint32_t *tw = truth + f * Kw;
-                    bool differs = false;
-                    pack_bits_group<64>(K, d.lane, 0, info_bit, [&](int wi, uint32_t v) { differs |= (v != tw[wi]); });
-                    ok = !differs;
-                } else {
-                    uint32_t syn = 0u;
-                    for (int k = d.lane; k < K; k += 64)
-                        if (info_bit(k)) syn ^= crcS[k];
-                    for (int off = 1; off < 64; off <<= 1) syn ^= (uint32_t)__shfl_xor((int)syn, off, 64);
-                    ok = syn == 0u;
+        // the list itself, in metric order
+        if (pm_out && d.h == 0 && d.p < LMAX) pm_out[f * LMAX + (act ? rank : d.p)] = act ? (double)d.pm : -INFINITY;
+        if (u_hat_all) {
+            for (int r = 0; r < LMAX; r++) {
+                uint32_t *row = u_hat_all + ((size_t)f * LMAX + r) * NW;
+                if (r < d.Lcur) {
+                    path_words((int)inv[r]);
+                    if (d.lane < NW) row[d.lane] = uw[d.lane];
+                } else if (d.lane < NW) {
+                    row[d.lane] = 0u;
                 }
-                if (ok) sel = r;
             }
-            if (sel < 0) path_words((int)inv[0]);
-        } else {
-            path_words((int)inv[0]);
         }
-        uint32_t *dst = info_hat + f * Kw;
-        pack_bits_group<64>(K, d.lane, 0, info_bit, [&](int wi, uint32_t v) {
-            if (d.lane == 0) dst[wi] = v;
-        });
-        if (K == 0 && d.lane == 0) dst[0] = 0u;
+        if (info_hat) {
+            if (crcS || truth) {
+                // aided choice: the first path in metric order that passes, the best one if none does
+                int sel = -1;
+                for (int r = 0; r < d.Lcur && sel < 0; r++) {
+                    path_words((int)inv[r]);
+                    bool ok;
+                    if (truth) {
+                        const uint32_t *tw = truth + f * Kw;
+                        bool differs = false;
+                        pack_bits_group<64>(K, d.lane, 0, info_bit, [&](int wi, uint32_t v) { differs |= (v != tw[wi]); });
+                        ok = !differs;
+                    } else {
+                        uint32_t syn = 0u;
+                        for (int k = d.lane; k < K; k += 64)
+                            if (info_bit(k)) syn ^= crcS[k];
+                        for (int off = 1; off < 64; off <<= 1) syn ^= (uint32_t)__shfl_xor((int)syn, off, 64);
+                        ok = syn == 0u;
+                    }
+                    if (ok) sel = r;
+                }
+                if (sel < 0) path_words((int)inv[0]);
+            } else {
+                path_words((int)inv[0]);
+            }
+            uint32_t *dst = info_hat + f * Kw;
+            pack_bits_group<64>(K, d.lane, 0, info_bit, [&](int wi, uint32_t v) {
+                if (d.lane == 0) dst[wi] = v;
+            });
+            if (K == 0 && d.lane == 0) dst[0] = 0u;
+        }
         wave_sync();
     }
 }
 
-template <int NLOG, int LMAX> int launch_wide_t(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, bool crc, const uint32_t *truth)
+template <int NLOG, int LMAX, typename T>
+int launch_wide_t(polar_code *c, const void *llr, uint32_t *info_hat, double *pm, uint32_t *u_hat_all, int64_t B, bool crc,
+                  const uint32_t *truth)
 {
     polar_ctx *ctx = c->ctx;
-    auto kern = scl_wide_kernel<NLOG, LMAX>;
+    auto kern = scl_wide_kernel<NLOG, LMAX, T>;
     int occ = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, 0));
     if (occ < 1) occ = 1;
     const int64_t grid = std::min<int64_t>(B, (int64_t)ctx->num_cus * occ);
     int rc;
-    if ((rc = ctx->scl_slab.reserve(std::max<size_t>(4, (size_t)grid * WideStore<NLOG>::MEM_ROWS * 64 * sizeof(float))))) return rc;
+    if ((rc = ctx->scl_slab.reserve(std::max<size_t>(4, (size_t)grid * WideStore<NLOG, T>::MEM_ROWS * 64 * sizeof(T))))) return rc;
     LaunchTimer tm(ctx);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), 0, ctx->stream, (const float *)llr, (const uint32_t *)c->d_maskw,
-                       (const uint32_t *)c->d_A, info_hat, B, c->K, c->Kw, ctx->scl_slab.as<float>(),
-                       crc ? (const uint32_t *)c->d_crcS : (const uint32_t *)nullptr, truth);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), 0, ctx->stream, (const T *)llr, (const uint32_t *)c->d_maskw,
+                       (const uint32_t *)c->d_A, info_hat, B, c->K, c->Kw, ctx->scl_slab.as<T>(),
+                       crc ? (const uint32_t *)c->d_crcS : (const uint32_t *)nullptr, truth, pm, u_hat_all);
     HIP_TRY(hipGetLastError());
     const float ms = tm.stop();
-    snprintf(c->last.kernel, sizeof(c->last.kernel), "scl_wide_kernel<%d>/L%d", NLOG, LMAX);
+    snprintf(c->last.kernel, sizeof(c->last.kernel), sizeof(T) == 4 ? "scl_wide_kernel<%d>/L%d" : "scl_wide_kernel<%d,double>/L%d", NLOG, LMAX);
     c->last.lanes_per_frame = 64;
-    c->last.lds_bytes_per_block = 4 * c->N + 384 + 4 * WideStore<NLOG>::LDS_VALUES;
+    c->last.lds_bytes_per_block = (int)sizeof(T) * (c->N + WideStore<NLOG, T>::LDS_VALUES) + 128 + 64 * (int)sizeof(typename KeyOf<T>::type);
     c->last.block_threads = 64;
     c->last.grid_blocks = (int)grid;
     c->last.last_ms = ms;
     return POLAR_OK;
 }
 
-template <int NLOG> int launch_wide_l(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, int L, bool crc, const uint32_t *truth)
+template <int NLOG>
+int launch_wide_l(polar_code *c, const void *llr, int dtype, uint32_t *info_hat, double *pm, uint32_t *u_hat_all, int64_t B, int L, bool crc,
+                  const uint32_t *truth)
 {
-    if (L == 32) return launch_wide_t<NLOG, 32>(c, llr, info_hat, B, crc, truth);
-    return launch_wide_t<NLOG, 16>(c, llr, info_hat, B, crc, truth);
+    if (dtype == POLAR_F32) {
+        if (L == 32) return launch_wide_t<NLOG, 32, float>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
+        return launch_wide_t<NLOG, 16, float>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
+    }
+    if (L == 32) return launch_wide_t<NLOG, 32, double>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
+    return launch_wide_t<NLOG, 16, double>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
 }
 
 }  // namespace
 
 bool scl_wide_supported(const polar_code *c, int dtype, int L, const void *pm, const void *u_hat_all)
 {
-    if (dtype != POLAR_F32 || (L != 16 && L != 32) || pm || u_hat_all) return false;
+    if ((dtype != POLAR_F32 && dtype != POLAR_F64) || (L != 16 && L != 32)) return false;
+    // fp32 list outputs (metrics, every path) stay with the LDS-staged kernel, like the eight-lanes-per-path kernel's
+    if (dtype == POLAR_F32 && (pm || u_hat_all)) return false;
     if (c->n < 6 || c->n > 10 || c->K < 5) return false;
     const char *e = polar_switch("POLAR_SCL_KERNEL");
     if (e && e[0] == 'l') return false;  // "lds": force the LDS-staged kernel
     return true;
 }
 
-int launch_scl_wide(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, int L, bool crc, const uint32_t *truth)
+int launch_scl_wide(polar_code *c, const void *llr, int dtype, uint32_t *info_hat, double *pm, uint32_t *u_hat_all, int64_t B, int L,
+                    bool crc, const uint32_t *truth)
 {
     if (B == 0) return POLAR_OK;
     switch (c->n) {
-    case 6: return launch_wide_l<6>(c, llr, info_hat, B, L, crc, truth);
-    case 7: return launch_wide_l<7>(c, llr, info_hat, B, L, crc, truth);
-    case 8: return launch_wide_l<8>(c, llr, info_hat, B, L, crc, truth);
-    case 9: return launch_wide_l<9>(c, llr, info_hat, B, L, crc, truth);
-    case 10: return launch_wide_l<10>(c, llr, info_hat, B, L, crc, truth);
+    case 6: return launch_wide_l<6>(c, llr, dtype, info_hat, pm, u_hat_all, B, L, crc, truth);
+    case 7: return launch_wide_l<7>(c, llr, dtype, info_hat, pm, u_hat_all, B, L, crc, truth);
+    case 8: return launch_wide_l<8>(c, llr, dtype, info_hat, pm, u_hat_all, B, L, crc, truth);
+    case 9: return launch_wide_l<9>(c, llr, dtype, info_hat, pm, u_hat_all, B, L, crc, truth);
+    case 10: return launch_wide_l<10>(c, llr, dtype, info_hat, pm, u_hat_all, B, L, crc, truth);
     default: polar_set_error("wide list kernel: unsupported length"); return POLAR_EUNSUPPORTED;
     }
 }

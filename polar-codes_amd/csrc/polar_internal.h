@@ -123,9 +123,10 @@ bool scl_reg_supported(const polar_code *c, int dtype, int L, const void *pm, co
 // truth (packed [B x Kw], or NULL): genie-aided choice of the output path
 int launch_scl_reg(polar_code *c, const void *llr, int dtype, uint32_t *info_hat, double *pm, uint32_t *u_hat_all, int64_t B, bool crc,
                    const uint32_t *truth, int L);
-// the two-lanes-per-path register kernel for L = 16 / 32 (plain list decoding, best path only)
+// the two-lanes-per-path register kernel for L = 16 / 32 (fp32: best path only; fp64: also the sorted list and its metrics)
 bool scl_wide_supported(const polar_code *c, int dtype, int L, const void *pm, const void *u_hat_all);
-int launch_scl_wide(polar_code *c, const void *llr, uint32_t *info_hat, int64_t B, int L, bool crc, const uint32_t *truth);
+int launch_scl_wide(polar_code *c, const void *llr, int dtype, uint32_t *info_hat, double *pm, uint32_t *u_hat_all, int64_t B, int L,
+                    bool crc, const uint32_t *truth);
 int launch_scl_decode(polar_code *c, const void *llr, int dtype, int L, uint32_t *info_hat, double *pm,
                       uint32_t *u_hat_all, int64_t B, bool crc, const uint32_t *truth);
 // nbits: leading bits of each K-bit word that are compared

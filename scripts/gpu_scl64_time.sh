@@ -7,8 +7,8 @@ import sys, os; sys.path[:0]=['polar-codes_amd','.']
 import numpy as np, torch, _native, functions as pcf
 from channel import Channel
 ctx=_native.default_ctx(0); ctx.enable_timing(True)
-for (N,K,L,snr,nb,dt) in [(1024,512,8,2.0,1<<18,np.float64),(1024,512,8,1.0,1<<17,np.float64),(512,256,8,2.0,1<<18,np.float64),(512,256,32,2.0,1<<13,np.float64),(256,128,4,2.0,1<<14,np.float64)]:
-    code=_native.Code(ctx,pcf.degaBuild(N,K,2.0)); n0=Channel('BPSK',snr,'SNRb',K/N).noisePower
+for (N,K,L,snr,nb,dt) in [(1024,512,8,2.0,1<<18,np.float64),(1024,512,8,1.0,1<<17,np.float64),(512,256,8,2.0,1<<18,np.float64),(512,256,32,2.0,1<<16,np.float64),(512,256,16,2.0,1<<16,np.float64),(1024,512,32,2.0,1<<15,np.float64),(256,128,4,2.0,1<<14,np.float64)]:
+    code=_native.Code(ctx,pcf.rmPolarBuild(N,K,2.0) if (N,L)==(512,32) else pcf.degaBuild(N,K,2.0)); n0=Channel('BPSK',snr,'SNRb',K/N).noisePower
     tdt=torch.float64 if dt is np.float64 else torch.float32
     llr=torch.empty((nb,N),dtype=tdt,device='cuda'); info=torch.empty((nb,code.Kw),dtype=torch.int32,device='cuda'); hat=torch.empty_like(info)
     code.gen_frames_dev(info.data_ptr(),llr.data_ptr(),dt,n0,1,0,nb)

@@ -37,6 +37,12 @@ def test_scl_fp64_matches_reference_vectors(golden, cons, N, K, L, snr):
     frames = [make_frame(pc.polarMask, snr, int(s), oracle.polar_encode) for s in seeds]
     llr = np.stack([f[2] for f in frames])
     dec = pc.sclDecoder(llr)
+    if 64 <= N <= 1024 and L > 1 and K >= 5:
+        # the reference's arithmetic (fp64) with the whole list as output runs on the register kernels: eight lanes per
+        # path up to L = 8, two lanes per path for L = 16 / 32
+        want = "scl_reg_kernel" if L <= 8 else "scl_wide_kernel"
+        kern = pc.native.last_launch()["kernel"]
+        assert kern.startswith(want) and "double" in kern, kern
     assert (g[f"{tag}_gap"] > 1e-9).all()  # no stored frame is sensitive to last-ulp metric differences
     assert np.array_equal(pack(dec), g[f"{tag}_dec"])
     for f in range(len(seeds)):
@@ -272,6 +278,36 @@ def test_scl_fp64_register_kernel_equals_lds_kernel(monkeypatch, N, K, L):
     monkeypatch.delenv("POLAR_SCL_KERNEL", raising=False)
     a, apm, auh = code.scl_decode(llr, L, want_list=True)
     assert code.last_launch()["kernel"].startswith("scl_reg_kernel") and "double" in code.last_launch()["kernel"], code.last_launch()
+    a2, _, _ = code.scl_decode(llr, L)  # without the list outputs
+    monkeypatch.setenv("POLAR_SCL_KERNEL", "lds")
+    b, bpm, buh = code.scl_decode(llr, L, want_list=True)
+    assert code.last_launch()["kernel"].startswith("scl_decode_kernel")
+    assert np.array_equal(a, b), np.flatnonzero(np.any(a != b, axis=1))[:20]
+    assert np.array_equal(a2, b)
+    assert np.array_equal(auh, buh), np.flatnonzero(np.any(auh != buh, axis=(1, 2)))[:20]
+    assert np.array_equal(apm, bpm), np.flatnonzero(np.any(apm != bpm, axis=1))[:20]
+
+
+@pytest.mark.parametrize("L", [32, 16])
+@pytest.mark.parametrize("cons,N,K", [("dega", 64, 32), ("dega", 128, 64), ("dega", 256, 128), ("rmpolar", 512, 256), ("dega", 512, 150),
+                                      ("dega", 1024, 512)])
+def test_scl_fp64_wide_kernel_equals_lds_kernel(monkeypatch, cons, N, K, L):
+    """fp64 with lists of 16 and 32 paths (what PolarCode.sclDecoder runs by default at those list sizes): the
+    two-lanes-per-path register kernel against the LDS-staged kernel, whole sorted list.  Same operations in the same
+    order: decoded bits, every survivor and every metric identical to the last bit, including frames with integer LLRs
+    (exactly tied candidate metrics) and frames whose wrong decisions overflow to -inf."""
+    mask = pcf.degaBuild(N, K, 2.0) if cons == "dega" else pcf.rmPolarBuild(N, K, 2.0)
+    code = _native.Code(_native.default_ctx(), mask)
+    rs = np.random.RandomState(N + K + L + 1)
+    B = 301
+    x = oracle.polar_encode(rs.randint(0, 2, size=(B, K)), mask).reshape(B, N)
+    n0 = 1.0 / (K / N * 10 ** (1.0 / 10))
+    llr = code.channel_llr(x, n0, 19, 0, np.float64)
+    llr[:40] = np.round(llr[:40])
+    llr[40:44] *= 200.0
+    monkeypatch.delenv("POLAR_SCL_KERNEL", raising=False)
+    a, apm, auh = code.scl_decode(llr, L, want_list=True)
+    assert code.last_launch()["kernel"].startswith("scl_wide_kernel") and "double" in code.last_launch()["kernel"], code.last_launch()
     a2, _, _ = code.scl_decode(llr, L)  # without the list outputs
     monkeypatch.setenv("POLAR_SCL_KERNEL", "lds")
     b, bpm, buh = code.scl_decode(llr, L, want_list=True)
