@@ -66,17 +66,34 @@ def _mask_id(pcode):
     return hashlib.sha1(np.ascontiguousarray(np.asarray(pcode.polarMask) != 0, dtype=np.uint8).tobytes()).hexdigest()[:16]
 
 
-def _checkpoint_load(path, ident):
-    """State of an earlier, interrupted sweep with the same arguments, or an empty one."""
+def _checkpoint_load(path, ident, rank=0, dist=None):
+    """State of an earlier, interrupted sweep with the same arguments, or an empty one.
+
+    Only rank 0 reads the file (it is the only writer as well) and every other rank receives what rank 0 found:
+    ranks that looked for themselves could see different contents (no shared file system, a stale cache) and then
+    disagree about which points are finished -- one would skip an all-reduce the others wait in."""
     import json
 
-    if path and os.path.exists(path):
-        with open(path) as fh:
-            state = json.load(fh)
-        if state.get("ident") != ident:
-            raise ValueError("checkpoint %s was written for another sweep: %r" % (path, state.get("ident")))
-        return state
-    return {"ident": ident, "points": {}}
+    found = None
+    if rank == 0:
+        try:
+            if path and os.path.exists(path):
+                with open(path) as fh:
+                    state = json.load(fh)
+                if state.get("ident") != ident:
+                    raise ValueError("checkpoint %s was written for another sweep: %r" % (path, state.get("ident")))
+                found = state
+            else:
+                found = {"ident": ident, "points": {}}
+        except Exception as e:  # the other ranks must hear of it too, or they wait in the broadcast for ever
+            found = e
+    if dist is not None:
+        box = [found]
+        dist.broadcast_object_list(box, src=0)
+        found = box[0]
+    if isinstance(found, Exception):
+        raise found
+    return found
 
 
 def _checkpoint_save(path, state, rank):
@@ -180,7 +197,7 @@ def simulate(pcode, snrRange, frames=None, errCnt=100, minFrames=100000, maxFram
              "dtype": np.dtype(dtype).name, "snrType": snrType, "modu": modu, "isCRC": isCRC, "genie": bool(genie), "seed": int(seed),
              "snrRange": [float(v) for v in snrRange], "frames": None if frames is None else int(frames), "errCnt": int(errCnt),
              "minFrames": int(minFrames), "maxFrames": int(maxFrames), "batch": int(batch), "world": int(world)}
-    state = _checkpoint_load(checkpoint, ident)
+    state = _checkpoint_load(checkpoint, ident, rank, dist)
     for ip, snr in enumerate(snrRange):
         snr = float(snr)
         if verbose and rank == 0:

@@ -101,6 +101,65 @@ def test_two_rank_gloo_job_gives_single_rank_totals(tmp_path):
     assert r0[3][0] % 200 == 0 and r0[3][0] >= 300 and r0[4][0] >= 40
 
 
+RESUME_WORKER = r'''
+import os, sys, json
+sys.path[:0] = [%(root)r, %(root)r + "/polar-codes_amd", %(root)r + "/tests"]
+import torch.distributed as dist
+import simulator
+from test_simulator import FakeCode, oracle_runner
+dist.init_process_group("gloo")
+rank = dist.get_rank()
+pc = FakeCode(64, 32)
+# each rank is given its own path: only rank 0's file exists, as on ranks without a shared file system
+ck = os.path.join(%(out)r, "ck_rank%%d.json" %% rank)
+kw = dict(frames=None, errCnt=30, minFrames=800, batch=100, seed=4, verbose=False)
+phase = %(phase)r
+if phase == "first":
+    calls = [0]
+    inner = oracle_runner(pc)
+    def dying(N0, seed, f0, n):
+        calls[0] += 1
+        if calls[0] > 5:          # both ranks die in the same round of the second point
+            raise RuntimeError("killed")
+        return inner(N0, seed, f0, n)
+    try:
+        simulator.simulate(pc, [0.0, 1.0], runner=dying, checkpoint=ck, **kw)
+    except RuntimeError:
+        pass
+else:
+    log = []
+    res = simulator.simulate(pc, [0.0, 1.0], runner=oracle_runner(pc, log), checkpoint=ck, **kw)
+    open(os.path.join(%(out)r, "resume%%d.json" %% rank), "w").write(json.dumps([res.frames, res.frameErrors, res.bitErrors, len(log)]))
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_resume_takes_the_checkpoint_from_rank_0(tmp_path):
+    """Only rank 0 can see the checkpoint file (every rank is handed a path of its own, and only rank 0 ever writes one):
+    the state found by rank 0 is broadcast, so both ranks skip the finished point, continue the interrupted one at the same
+    round, enter the same all-reduces and end with the totals of an uninterrupted single-rank sweep."""
+    import json
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    for phase, port in (("first", "29541"), ("second", "29542")):
+        script = tmp_path / ("resume_%s.py" % phase)
+        script.write_text(RESUME_WORKER % {"root": ROOT, "out": str(tmp_path), "phase": phase})
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                              "127.0.0.1", "--master-port", port, str(script)], capture_output=True, text=True, env=env, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert (tmp_path / "ck_rank0.json").exists() and not (tmp_path / "ck_rank1.json").exists()
+    r0, r1 = (json.loads((tmp_path / ("resume%d.json" % r)).read_text()) for r in (0, 1))
+    assert r0[:3] == r1[:3], "every rank reports the all-reduced totals"
+    assert r0[3] == r1[3], "both ranks ran the same number of batches after the resume"
+    pc = FakeCode(64, 32)
+    log = []
+    # the uninterrupted sweep with the same frame layout: one rank, rounds of world * batch frames
+    single = simulator.simulate(pc, [0.0, 1.0], frames=None, errCnt=30, minFrames=800, batch=200, seed=4, runner=oracle_runner(pc, log),
+                                verbose=False)
+    assert r0[0] == single.frames and r0[1] == single.frameErrors and r0[2] == single.bitErrors
+    assert 1 <= r0[3] < len(log)  # fewer rounds than a sweep from the start
+
+
 def test_bench_gpus_flag_starts_that_many_ranks():
     """`bench.py --gpus 2` without a launcher starts two ranks itself, before any GPU call of its own; without a GPU every
     rank stops with the same message and the exit code is passed on."""
