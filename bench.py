@@ -31,17 +31,23 @@ VALU_PEAK_TLOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 
 
 def measured_traffic(kernel_name, frames):
-    """HBM bytes per launch from the rocprofv3 PMC passes recorded in profiles/traffic.json
-    ({kernel prefix: bytes per frame}, = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 / frames, with the
-    gfx950 FETCH_SIZE correction), or None when no measurement is on file for this kernel."""
+    """(HBM bytes per launch, where that figure comes from) for a kernel.  The figure is NOT measured by this run: it is
+    looked up in profiles/traffic.json, which tools/refresh_profiles.py writes from separate rocprofv3 PMC passes
+    ({kernel prefix: {bytes_per_frame, what, commit, date, file}}; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 / frames,
+    with the gfx950 FETCH_SIZE correction), scaled by the frames of this launch.  (None, None) when no pass is on file."""
     try:
         tab = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     except (OSError, ValueError):
-        return None
+        return None, None
     for k, v in tab.items():
-        if kernel_name.startswith(k):
-            return v * frames
-    return None
+        if k.startswith("_") or not kernel_name.startswith(k):
+            continue
+        if isinstance(v, dict):
+            src = {key: v.get(key) for key in ("file", "commit", "date", "what", "frames_per_launch")}
+            src["lookup"] = "profiles/traffic.json (static table from earlier PMC passes, scaled to this launch)"
+            return v["bytes_per_frame"] * frames, src
+        return v * frames, {"lookup": "profiles/traffic.json (static table from earlier PMC passes, scaled to this launch)"}
+    return None, None
 
 
 def leg_roofline(kernel, kernel_ms, frames, N, K, paths=1, hbm_bytes_per_frame=None):
@@ -52,8 +58,9 @@ def leg_roofline(kernel, kernel_ms, frames, N, K, paths=1, hbm_bytes_per_frame=N
     ops = paths * 3.5 * N * np.log2(N)
     byts = (4 * N + K / 8) if hbm_bytes_per_frame is None else hbm_bytes_per_frame
     secs = kernel_ms * 1e-3
+    traffic, traffic_source = measured_traffic(kernel, frames)
     return {"bound": "valu", "achieved": ops * frames / secs / 1e12, "peak": VALU_PEAK_TLOPS, "unit": "Tlane-op/s",
-            "frac": ops * frames / secs / 1e12 / VALU_PEAK_TLOPS, "traffic": measured_traffic(kernel, frames),
+            "frac": ops * frames / secs / 1e12 / VALU_PEAK_TLOPS, "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_lane_ops_per_frame": ops, "algorithmic_bytes_per_frame": byts,
             "hbm_GBs_algorithmic": byts * frames / secs / 1e9, "hbm_frac": byts * frames / secs / 1e9 / HBM_PEAK_GBS,
             "kernel": kernel, "kernel_ms": kernel_ms}
@@ -185,27 +192,47 @@ def main():
         torch.cuda.synchronize()
 
     def step():
+        """One step; returns (seconds until this rank's decode + count had finished, seconds of the counter all-reduce)."""
         counters = counter_rows[step_no[0]]
         step_no[0] += 1
+        s0 = time.perf_counter()
         # decode, store the extracted information words and count the errors against the transmitted ones, one pass
         code.sc_decode_count_dev(llr.data_ptr(), np.float32, info.data_ptr(), B, counters.data_ptr(), fast=True,
                                  info_hat_ptr=hat.data_ptr())
         ctx.sync()
+        s1 = time.perf_counter()
         if world > 1:
             all_reduce(counters)
+            torch.cuda.synchronize()  # the step is over when its counters are summed
+        return s1 - s0, time.perf_counter() - s1
+
+    def over_ranks(values):
+        """{name: {"per_rank": [...], "min": .., "max": ..}} of this rank's float values, gathered over the ranks."""
+        names = list(values)
+        mine = torch.tensor([float(values[k]) for k in names], dtype=torch.float64, device=dev)
+        if world > 1:
+            if backend == "nccl":
+                rows = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(rows, mine)
+            else:
+                rows = [torch.empty_like(mine.cpu()) for _ in range(world)]
+                dist.all_gather(rows, mine.cpu())
+            tab = torch.stack([r.cpu() for r in rows])
+        else:
+            tab = mine.cpu()[None]
+        return {k: {"per_rank": tab[:, i].tolist(), "min": float(tab[:, i].min()), "max": float(tab[:, i].max())} for i, k in enumerate(names)}
 
     for _ in range(a.warmup):
         step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
+    parts = [step() for _ in range(a.steps)]
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         all_reduce(tmax, dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    my_dt, dt = dt, float(tmax.item())
     cnt = counter_rows[step_no[0] - 1].cpu().tolist()
 
     # live kernel timing: HIP events on the library's launch stream around the decode kernel alone
@@ -217,28 +244,53 @@ def main():
     ctx.enable_timing(False)
     launch = code.last_launch()
     k_ms = float(np.mean(kms))
+    # where a step's time goes on every rank: a scaling loss shows as a slow rank (kernel), a long wait in the collective
+    # (the slowest rank's decode ends later than mine) or neither (launch / host)
+    per_rank = over_ranks({"kernel_ms": k_ms, "decode_and_count_ms_per_step": 1e3 * sum(p_[0] for p_ in parts) / a.steps,
+                           "allreduce_ms_per_step": 1e3 * sum(p_[1] for p_ in parts) / a.steps,
+                           "wall_ms_per_step": 1e3 * my_dt / a.steps})
 
-    # secondary leg, all ranks: SCL L=8 on the first 2^20 frames of each rank's batch, counters all-reduced
+    # secondary leg, all ranks: SCL L=8 on the first 2^20 frames of each rank's batch, counters all-reduced after every step;
+    # one warm-up step, then SCL_STEPS timed ones between barriers; kernel time per rank from the HIP events
     scl = None
+    SCL_STEPS = 3
     if not a.no_extras:
         nb = min(B, 1 << 20)
-        c2 = torch.zeros(3, dtype=torch.int64, device=dev)
-        code.scl_decode_dev(llr.data_ptr(), np.float32, 8, hat.data_ptr(), nb)  # warm-up
+        c2rows = torch.zeros((SCL_STEPS + 1, 3), dtype=torch.int64, device=dev)
+        ctx.enable_timing(True)  # the events only add the wait for the kernel, which the step needs anyway before it counts
+
+        def scl_step(i):
+            s0 = time.perf_counter()
+            code.scl_decode_dev(llr.data_ptr(), np.float32, 8, hat.data_ptr(), nb)
+            kms_ = code.last_launch()["last_ms"]
+            code.count_errors_dev(info.data_ptr(), hat.data_ptr(), nb, c2rows[i].data_ptr())
+            ctx.sync()
+            s1 = time.perf_counter()
+            if world > 1:
+                all_reduce(c2rows[i])
+                torch.cuda.synchronize()
+            return kms_, s1 - s0, time.perf_counter() - s1
+
+        scl_step(SCL_STEPS)  # warm-up
         barrier()
         t0 = time.perf_counter()
-        code.scl_decode_dev(llr.data_ptr(), np.float32, 8, hat.data_ptr(), nb)
-        code.count_errors_dev(info.data_ptr(), hat.data_ptr(), nb, c2.data_ptr())
-        ctx.sync()
-        if world > 1:
-            all_reduce(c2)
+        sparts = [scl_step(i) for i in range(SCL_STEPS)]
         barrier()
-        sdt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        my_sdt = time.perf_counter() - t0
+        ctx.enable_timing(False)
+        sdt = torch.tensor([my_sdt], dtype=torch.float64, device=dev)
         if world > 1:
             all_reduce(sdt, dist.ReduceOp.MAX)
-        c2 = c2.cpu().tolist()
-        scl = {"frames_per_s": nb * world / float(sdt.item()), "info_mbps": nb * world * K / float(sdt.item()) / 1e6,
-               "frames_per_gpu": nb, "fer": c2[1] / max(c2[0], 1), "kernel": code.last_launch()["kernel"],
-               "note": "wall time of decode + count + counter all-reduce, max over ranks"}
+        sdt = float(sdt.item())
+        c2 = c2rows[0].cpu().tolist()
+        scl = {"frames_per_s": nb * world * SCL_STEPS / sdt, "info_mbps": nb * world * SCL_STEPS * K / sdt / 1e6,
+               "frames_per_gpu": nb, "steps": SCL_STEPS, "warmup": 1, "ms_per_step": 1e3 * sdt / SCL_STEPS,
+               "fer": c2[1] / max(c2[0], 1), "kernel": code.last_launch()["kernel"],
+               "note": "wall time of SCL_STEPS x (decode + count + counter all-reduce) between barriers, max over ranks",
+               "per_rank": over_ranks({"kernel_ms": float(np.mean([p_[0] for p_ in sparts])),
+                                       "decode_and_count_ms_per_step": 1e3 * sum(p_[1] for p_ in sparts) / SCL_STEPS,
+                                       "allreduce_ms_per_step": 1e3 * sum(p_[2] for p_ in sparts) / SCL_STEPS,
+                                       "wall_ms_per_step": 1e3 * my_sdt / SCL_STEPS})}
 
     out = None
     if rank == 0:
@@ -272,13 +324,15 @@ def main():
         "specialize_s": specialize_s,
         "specialize_error": specialize_error,
             "scl8": scl,
+            "per_rank": per_rank,
             "roofline": {
                 "bound": "hbm",
                 "achieved": alg_hbm / (k_ms * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": alg_hbm / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "traffic": measured_traffic(launch["kernel"], B),
+                "traffic": measured_traffic(launch["kernel"], B)[0],
+                "traffic_source": measured_traffic(launch["kernel"], B)[1],
                 "kernel": launch["kernel"],
                 "kernel_ms": k_ms,
                 "algorithmic_bytes_per_frame": 4 * N + K / 8,
