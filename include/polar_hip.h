@@ -161,6 +161,20 @@ int polar_scl_decode_genie(polar_code *code, const void *llr, int dtype, int L, 
 int polar_scl_decode_genie_packed(polar_code *code, const void *llr, int dtype, int L, const uint32_t *info_true,
                                   uint32_t *info_hat, double *pm_sorted, uint32_t *u_hat_all, int64_t B, int space);
 
+/* ---- which kernel serves a call ---------------------------------------------------------------------
+ *      The reference dispatches on a string (PolarCode.decode, cn/polarCode.py:316-350); this library on one static table
+ *      (kernel family x arithmetic x log2 N range x list sizes x smallest K x outputs x properties of the call), read in
+ *      order by every decoder entry point.  Both functions are host-only and need no GPU.
+ *      polar_dispatch_select: row of the table that would serve the call, its kernel name into kernel[0..kernel_len), or
+ *      POLAR_EUNSUPPORTED with a message for a call no kernel covers.  op: 0 = SC, 1 = SCL, 2 = flip search, 3 = the SC
+ *      Monte-Carlo loop of polar_mc_run.  L: list size / largest number of simultaneous flips.  outputs: 1 information bits,
+ *      2 u_hat (SCL: every path of the list), 4 decision LLRs, 8 sorted metrics.  flags: 1 short-cut schedule
+ *      (POLAR_SC_FAST), 2 the code was specialised (polar_code_specialize), 4 CRC, 8 genie, 16 caller gives the flip list,
+ *      32 workspace of the two-flip search in pieces at hand, 64 / 128 the experiment switches "lds" / "generic".
+ *      polar_dispatch_table: the table as tab-separated text into buf[0..len); returns the bytes a complete copy needs. */
+int polar_dispatch_select(int op, int N, int K, int dtype, int L, int outputs, int flags, char *kernel, int kernel_len);
+int polar_dispatch_table(char *buf, int len);
+
 /* ---- bit flipping ---------------------------------------------------------------------------------
  *      Host-only: pcf.generateCriticalSet((polarMask + 1) % 2) for after < 0, pcf.modifyCriticalSet(polarMask,
  *      after) otherwise (cn/functions.py:279-319): first positions of the maximal all-information subtrees,

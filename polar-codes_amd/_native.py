@@ -64,6 +64,8 @@ SIGNATURES = {
     "polar_scl_decode_genie": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _i]),
     "polar_scl_decode_genie_packed": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _i]),
     "polar_critical_set": (_i, [_vp, _i, _i, _vp, _i]),
+    "polar_dispatch_select": (_i, [_i, _i, _i, _i, _i, _i, _i, _vp, _i]),
+    "polar_dispatch_table": (_i, [_vp, _i]),
     "polar_code_set_reliability": (_i, [_vp, _vp]),
     "polar_sc_decode_flip": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _i]),
     "polar_pbf_decode": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _i]),
@@ -403,6 +405,31 @@ def critical_set(mask, after=-1):
     if n < 0:
         _check(n)
     return out[:n].copy()
+
+
+# ---- which kernel serves a call (host only: the library's static dispatch table) ------------------------------------
+OP_SC, OP_SCL, OP_PBF, OP_MC_SC = 0, 1, 2, 3
+OUT_INFO, OUT_UHAT, OUT_DECLLR, OUT_PM = 1, 2, 4, 8
+DQ_FAST, DQ_SPECIALISED, DQ_CRC, DQ_GENIE, DQ_FLIP_LIST, DQ_SPLIT, DQ_FORCE_LDS, DQ_FORCE_GENERIC = 1, 2, 4, 8, 16, 32, 64, 128
+
+
+def dispatch_select(op, N, K, dtype, L=0, outputs=OUT_INFO, flags=0):
+    """(row of the dispatch table, kernel name) that serves the call; raises PolarError for a call no kernel covers."""
+    buf = C.create_string_buffer(96)
+    row = lib().polar_dispatch_select(int(op), int(N), int(K), _dt(dtype), int(L), int(outputs), int(flags), buf, len(buf))
+    if row < 0:
+        _check(row)
+    return row, buf.value.decode()
+
+
+def dispatch_table():
+    """The dispatch table as a list of dicts (one per row, in the order the launchers read it)."""
+    need = lib().polar_dispatch_table(None, 0)
+    buf = C.create_string_buffer(need)
+    lib().polar_dispatch_table(buf, need)
+    lines = buf.value.decode().strip().split("\n")
+    head = lines[0].split("\t")
+    return [dict(zip(head, ln.split("\t"))) for ln in lines[1:]]
 
 
 def default_ctx(device=None):

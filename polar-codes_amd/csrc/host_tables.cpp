@@ -129,3 +129,74 @@ std::vector<uint32_t> build_compress_tables(const uint8_t *mask, int N)
     }
     return tab;
 }
+
+
+// ---- kernel dispatch table ----------------------------------------------------------------------------------------------
+namespace {
+constexpr unsigned F32 = 1u, F64 = 2u;
+// list sizes / flip counts served, as a mask over 1 .. 32 (bit L - 1)
+constexpr unsigned LM(int a, int b = 0, int c = 0, int d = 0, int e = 0, int f = 0)
+{
+    return (a ? 1u << (a - 1) : 0u) | (b ? 1u << (b - 1) : 0u) | (c ? 1u << (c - 1) : 0u) | (d ? 1u << (d - 1) : 0u) |
+           (e ? 1u << (e - 1) : 0u) | (f ? 1u << (f - 1) : 0u);
+}
+constexpr unsigned ALL_SC = DQ_OUT_INFO | DQ_OUT_UHAT | DQ_OUT_DECLLR, ALL_SCL = DQ_OUT_INFO | DQ_OUT_UHAT | DQ_OUT_PM;
+const DispatchRow TABLE[] = {
+    // ---- SC (polar_sc_decode*, polar_sc_decode_count, the SC passes of polar_mc_run's staged pipeline)
+    {DQ_OP_SC, KF_SC_STATIC, "sc_static_kernel", F32, 5, 10, 0, 1, DQ_OUT_INFO, 0, DQ_FAST | DQ_SPECIALISED | DQ_INTERIOR_K, DQ_FORCE_LDS | DQ_FORCE_GENERIC,
+     "register-resident, compiled per code at run time"},
+    {DQ_OP_SC, KF_SC_REG, "sc_reg_kernel", F32, 5, 10, 0, 1, DQ_OUT_INFO, 0, DQ_INTERIOR_K, DQ_FORCE_LDS, "register-resident, any code (both schedules)"},
+    {DQ_OP_SC, KF_SC_REG_FULL, "sc_reg_full_kernel<double", F64, 5, 10, 0, 0, ALL_SC, 0, 0, DQ_FORCE_LDS,
+     "register-resident, every leaf, fp64 (the reference's arithmetic), u_hat and decision LLRs"},
+    {DQ_OP_SC, KF_SC_REG_FULL, "sc_reg_full_kernel<float", F32, 5, 10, 0, 0, ALL_SC, DQ_OUT_UHAT | DQ_OUT_DECLLR, 0, DQ_FORCE_LDS | DQ_FAST,
+     "register-resident, every leaf, fp32 with u_hat / decision LLRs"},
+    {DQ_OP_SC, KF_SC_BIG, "sc_big_kernel", F32, 11, 16, 0, 1, DQ_OUT_INFO, 0, DQ_FAST | DQ_INTERIOR_K, DQ_FORCE_LDS,
+     "long codes: wide levels in a global slab, 1024-leaf subtrees in registers"},
+    {DQ_OP_SC, KF_SC_LDS, "sc_decode_kernel<float", F32, 0, 16, 0, 0, ALL_SC, 0, 0, 0, "LDS-staged, any code, every output"},
+    {DQ_OP_SC, KF_SC_LDS, "sc_decode_kernel<double", F64, 0, 15, 0, 0, ALL_SC, 0, 0, 0, "LDS-staged, fp64"},
+    // ---- SCL (polar_scl_decode*, genie and CRC variants, the list passes of polar_mc_run)
+    {DQ_OP_SCL, KF_SCL_REG, "scl_reg_kernel<", F32, 6, 10, LM(2, 4, 8), 3, DQ_OUT_INFO, 0, 0, DQ_FORCE_LDS, "register-resident, eight lanes per path"},
+    {DQ_OP_SCL, KF_SCL_REG, "scl_reg_kernel<", F64, 6, 10, LM(2, 4, 8), 3, ALL_SCL, 0, 0, DQ_FORCE_LDS,
+     "the same in fp64 with the sorted list and its metrics"},
+    {DQ_OP_SCL, KF_SCL_WIDE, "scl_wide_kernel<", F32, 6, 10, LM(16, 32), 5, DQ_OUT_INFO, 0, 0, DQ_FORCE_LDS, "register-resident, two lanes per path"},
+    {DQ_OP_SCL, KF_SCL_WIDE, "scl_wide_kernel<", F64, 6, 10, LM(16, 32), 5, ALL_SCL, 0, 0, DQ_FORCE_LDS,
+     "the same in fp64 with the sorted list and its metrics"},
+    {DQ_OP_SCL, KF_SCL_LDS, "scl_decode_kernel<", F32 | F64, 0, 12, LM(1, 2, 4, 8, 16, 32), 0, ALL_SCL, 0, 0, 0, "LDS-staged, every output"},
+    // ---- progressive bit flipping (polar_pbf_decode*, polar_sc_decode_flip); L = largest number of simultaneous flips
+    {DQ_OP_PBF, KF_PBF_REG, "pbf_reg_kernel<", F32 | F64, 5, 10, LM(1), 1, DQ_OUT_INFO, 0, DQ_CRC, DQ_FORCE_LDS | DQ_FLIP_LIST,
+     "SC runs in registers, four flip candidates per wavefront, single flips"},
+    {DQ_OP_PBF, KF_PBF_REG, "pbf_reg_kernel<", F32 | F64, 5, 10, LM(2), 1, DQ_OUT_INFO, 0, DQ_CRC | DQ_SPLIT, DQ_FORCE_LDS | DQ_FLIP_LIST,
+     "the same for the two-flip search in pieces"},
+    {DQ_OP_PBF, KF_PBF_LDS, "pbf_decode_kernel<", F32 | F64, 0, 12, 0, 0, ALL_SC, 0, 0, 0,
+     "one wavefront per frame, LDS-staged SC runs: three flips, N > 1024, flip lists, side outputs"},
+    // ---- the SC Monte-Carlo loop of polar_mc_run
+    {DQ_OP_MC_SC, KF_MC_FUSED, "sc_static_mc_kernel", F32, 7, 10, 0, 1, 0, 0, DQ_FAST | DQ_SPECIALISED | DQ_INTERIOR_K, DQ_CRC | DQ_FORCE_GENERIC,
+     "draw, encode, channel, decode and count in one kernel, no LLR buffer"},
+    {DQ_OP_MC_SC, KF_MC_STAGED, "gen_frames_kernel + SC decoder", F32 | F64, 0, 16, 0, 0, 0, 0, 0, 0, "generator -> LLR buffer -> decoder, two streams"},
+};
+}  // namespace
+
+const DispatchRow *dispatch_table(int *count)
+{
+    if (count) *count = (int)(sizeof(TABLE) / sizeof(TABLE[0]));
+    return TABLE;
+}
+
+int dispatch_select(const DispatchQuery &q)
+{
+    const int N = q.n >= 0 && q.n < 31 ? 1 << q.n : 0;
+    const unsigned flags = ((unsigned)q.flags & ~(unsigned)DQ_INTERIOR_K) | ((q.K > 0 && q.K < N) ? (unsigned)DQ_INTERIOR_K : 0u);
+    const unsigned dt = q.dtype == 0 ? F32 : q.dtype == 1 ? F64 : 0u;
+    const int count = (int)(sizeof(TABLE) / sizeof(TABLE[0]));
+    for (int i = 0; i < count; i++) {
+        const DispatchRow &r = TABLE[i];
+        if (r.op != q.op || !(r.dtypes & dt)) continue;
+        if (q.n < r.n_min || q.n > r.n_max || q.K < r.k_min) continue;
+        if (r.l_mask && (q.L < 1 || q.L > 32 || !((r.l_mask >> (q.L - 1)) & 1u))) continue;
+        if ((unsigned)q.outputs & ~r.outputs_ok) continue;
+        if (r.outputs_any && !((unsigned)q.outputs & r.outputs_any)) continue;
+        if ((flags & r.need) != r.need || (flags & r.forbid)) continue;
+        return i;
+    }
+    return -1;
+}

@@ -47,3 +47,56 @@ void build_crc_tables(uint64_t crc_poly, int w, int K, std::vector<uint32_t> &E,
 // words, as (byte offset of the word) | (bit offset << 16).  Layout: word (4 g + i) of lane l at [(16 g + l) * 4 + i];
 // per lane words 0 .. 4 = mask, moves of slice word 0, 5 .. 9 = of slice word 1, 10 .. 13 = the four places.
 std::vector<uint32_t> build_compress_tables(const uint8_t *mask, int N);
+
+
+// ---- kernel dispatch table ----------------------------------------------------------------------------------------------
+// Which kernel family serves a call is decided by ONE table (dispatch_table), read in order: the first row whose
+// conditions hold wins, and a call no row covers is refused (POLAR_EUNSUPPORTED).  The launchers of every decoder entry
+// point, polar_dispatch_select / polar_dispatch_table of the C ABI and tests/test_dispatch.py all read this table.
+enum { DQ_OP_SC = 0, DQ_OP_SCL = 1, DQ_OP_PBF = 2, DQ_OP_MC_SC = 3 };
+enum {  // outputs a call asks for
+    DQ_OUT_INFO = 1,     // information bits of the decoded / chosen word
+    DQ_OUT_UHAT = 2,     // u_hat (SC: the word; SCL: every path of the list)
+    DQ_OUT_DECLLR = 4,   // decision LLRs (SC)
+    DQ_OUT_PM = 8        // sorted path metrics (SCL)
+};
+enum {  // properties of the call and of the code
+    DQ_FAST = 1,            // schedule with the rate-0 / rate-1 short-cuts (POLAR_SC_FAST)
+    DQ_SPECIALISED = 2,     // polar_code_specialize has built this code's own decoder
+    DQ_CRC = 4,             // CRC-aided choice / CRC-driven flip search
+    DQ_GENIE = 8,           // genie-aided choice
+    DQ_FLIP_LIST = 16,      // PBF: the caller gives the flip positions (polar_sc_decode_flip)
+    DQ_SPLIT = 32,          // PBF: the workspace of the two-flip search in pieces is at hand
+    DQ_FORCE_LDS = 64,      // experiment switch POLAR_*_KERNEL=lds
+    DQ_FORCE_GENERIC = 128, // experiment switch POLAR_SC_KERNEL=generic / POLAR_MC_KERNEL=staged
+    DQ_INTERIOR_K = 256     // set by dispatch_select itself: 0 < K < N
+};
+enum KernelFamily {
+    KF_SC_STATIC, KF_SC_REG, KF_SC_REG_FULL, KF_SC_BIG, KF_SC_LDS, KF_SCL_REG, KF_SCL_WIDE, KF_SCL_LDS, KF_PBF_REG, KF_PBF_LDS,
+    KF_MC_FUSED, KF_MC_STAGED
+};
+struct DispatchQuery {
+    int op;       // DQ_OP_*
+    int n;        // log2 N
+    int K;
+    int dtype;    // 0 = fp32, 1 = fp64 (POLAR_F32 / POLAR_F64)
+    int L;        // list size (SCL), largest number of simultaneous flips (PBF), else 0
+    int outputs;  // DQ_OUT_*
+    int flags;    // DQ_*
+};
+struct DispatchRow {
+    int op;
+    int family;
+    const char *kernel;     // kernel name as polar_last_launch reports it (prefix)
+    unsigned dtypes;        // bit 0: fp32, bit 1: fp64
+    int n_min, n_max;       // log2 N, inclusive
+    unsigned l_mask;        // bit L - 1 set = that L (1 .. 32) is served (0 = L is not looked at)
+    int k_min;              // smallest K served
+    unsigned outputs_ok;    // outputs the family can give
+    unsigned outputs_any;   // if non-zero: at least one of these must be asked for
+    unsigned need, forbid;  // flags that must / must not be set
+    const char *what;
+};
+const DispatchRow *dispatch_table(int *count);
+// index of the row that serves q, or -1
+int dispatch_select(const DispatchQuery &q);

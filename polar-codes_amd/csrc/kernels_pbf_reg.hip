@@ -400,12 +400,12 @@ template <typename T> int launch_pbf_reg_n(polar_code *c, PBFParams<T> &p, int64
 bool pbf_reg_supported(const polar_code *c, const uint32_t *rows, const int32_t *flips_in, int max_level, bool crc, const void *u_hat,
                        const void *dec_llr, const PbfSplit *split)
 {
-    if (!rows || flips_in || u_hat || dec_llr || !crc) return false;
-    if (c->n < 5 || c->n > 10 || c->K < 1 || c->K > 1024) return false;
-    if (!(max_level == 1 || (max_level == 2 && split))) return false;
-    const char *e = polar_switch("POLAR_PBF_KERNEL");
-    if (e && e[0] == 'l') return false;  // "lds": the LDS-staged search
-    return true;
+    // the table of host_tables.cpp says what this kernel serves; it works on the list of frames that failed their CRC, so a
+    // call without that list counts as a call with a flip list
+    DispatchQuery q{DQ_OP_PBF, c->n, c->K, 0, max_level, DQ_OUT_INFO | (u_hat ? DQ_OUT_UHAT : 0) | (dec_llr ? DQ_OUT_DECLLR : 0),
+                    (crc ? DQ_CRC : 0) | (split ? DQ_SPLIT : 0) | ((flips_in || !rows) ? DQ_FLIP_LIST : 0) | dq_switch_flags("POLAR_PBF_KERNEL")};
+    const int row = dispatch_select(q);
+    return row >= 0 && dispatch_table(nullptr)[row].family == KF_PBF_REG;
 }
 
 template <typename T> int launch_pbf_reg(polar_code *c, PBFParams<T> &p, int64_t B, const PbfSplit *split, int max_level)

@@ -330,9 +330,17 @@ int launch_sc_decode(polar_code *c, const void *llr, int dtype, uint32_t *info_h
                      int flags)
 {
     if (B == 0) return POLAR_OK;
-    if (sc_reg_supported(c, dtype, u_hat, dec_llr)) return launch_sc_reg(c, llr, dtype, info_hat, B, flags);
-    if (sc_reg_full_supported(c, dtype, u_hat, dec_llr, flags)) return launch_sc_reg_full(c, llr, dtype, info_hat, u_hat, dec_llr, B);
-    if (sc_big_supported(c, dtype, u_hat, dec_llr, flags)) return launch_sc_big(c, llr, info_hat, B);
-    if (dtype == POLAR_F32) return launch_sc_g<float>(c, llr, info_hat, u_hat, dec_llr, B, flags);
-    return launch_sc_g<double>(c, llr, info_hat, u_hat, dec_llr, B, flags);
+    switch (dispatch_sc(c, dtype, u_hat, dec_llr, flags)) {
+    case KF_SC_STATIC:
+    case KF_SC_REG: return launch_sc_reg(c, llr, dtype, info_hat, B, flags);
+    case KF_SC_REG_FULL: return launch_sc_reg_full(c, llr, dtype, info_hat, u_hat, dec_llr, B);
+    case KF_SC_BIG: return launch_sc_big(c, llr, info_hat, B);
+    case KF_SC_LDS:
+        if (dtype == POLAR_F32) return launch_sc_g<float>(c, llr, info_hat, u_hat, dec_llr, B, flags);
+        return launch_sc_g<double>(c, llr, info_hat, u_hat, dec_llr, B, flags);
+    default:
+        polar_set_error("SC decoder: no kernel serves N=%d, K=%d, %s with these outputs (polar_dispatch_table lists what is served)", c->N,
+                        c->K, dtype == POLAR_F32 ? "fp32" : "fp64");
+        return POLAR_EUNSUPPORTED;
+    }
 }

@@ -544,13 +544,7 @@ struct BigDeviceTables {
 
 bool sc_big_supported(const polar_code *c, int dtype, const void *u_hat, const void *dec_llr, int flags)
 {
-    if (u_hat || dec_llr) return false;
-    if (dtype != POLAR_F32 || !(flags & POLAR_SC_FAST)) return false;
-    if (c->n < 11 || c->n > 16) return false;
-    if (c->K == 0 || c->K == c->N) return false;
-    const char *e = polar_switch("POLAR_SC_KERNEL");
-    if (e && e[0] == 'l') return false;  // "lds": force the LDS-staged kernel
-    return true;
+    return dispatch_sc(c, dtype, u_hat, dec_llr, flags) == KF_SC_BIG;
 }
 
 static int build_big_tables(polar_code *c)

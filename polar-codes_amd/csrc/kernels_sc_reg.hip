@@ -159,26 +159,18 @@ static NodeClasses classify_nodes(const polar_code *c, bool fast)
     return nc;
 }
 
+// the predicates below ask the dispatch table (host_tables.cpp): one place says which kernel serves what
 bool sc_reg_supported(const polar_code *c, int dtype, const void *u_hat, const void *dec_llr)
 {
-    if (u_hat || dec_llr) return false;
-    if (c->n < 5 || c->n > 10) return false;
-    if (c->K == 0 || c->K == c->N) return false;  // root would be a rate-0 / rate-1 node
-    if (dtype != POLAR_F32) return false;  // fp64 (parity mode) runs on sc_reg_full_kernel or the LDS-staged kernel
-    const char *e = polar_switch("POLAR_SC_KERNEL");
-    if (e && e[0] == 'l') return false;  // "lds": force the LDS-staged kernel
-    return true;
+    // either schedule: the register kernels cover both (the specialised one needs the short-cut schedule and takes over there)
+    const int f = dispatch_sc(c, dtype, u_hat, dec_llr, POLAR_SC_FAST);
+    return f == KF_SC_STATIC || f == KF_SC_REG;
 }
 
 // every-leaf decoding with u_hat / decision LLRs, and all fp64 decoding, N = 32 .. 1024
 bool sc_reg_full_supported(const polar_code *c, int dtype, const void *u_hat, const void *dec_llr, int flags)
 {
-    if (c->n < 5 || c->n > 10) return false;
-    if (dtype == POLAR_F32 && !u_hat && !dec_llr) return false;  // the fp32 information-bit kernels are faster
-    if ((flags & POLAR_SC_FAST) && dtype == POLAR_F32) return false;
-    const char *e = polar_switch("POLAR_SC_KERNEL");
-    if (e && e[0] == 'l') return false;
-    return true;
+    return dispatch_sc(c, dtype, u_hat, dec_llr, flags) == KF_SC_REG_FULL;
 }
 
 template <typename T, int NLOG> static int launch_full_t(polar_code *c, const void *llr, uint32_t *info_hat, uint32_t *u_hat, void *dec_llr, int64_t B)
@@ -274,10 +266,7 @@ template <typename T> static int launch_reg_n(polar_code *c, const void *llr, ui
 int launch_sc_reg(polar_code *c, const void *llr, int dtype, uint32_t *info_hat, int64_t B, int flags)
 {
     if (B == 0) return POLAR_OK;
-    if (c->static_fn && (flags & POLAR_SC_FAST) && dtype == POLAR_F32) {
-        const char *e = polar_switch("POLAR_SC_KERNEL");
-        if (!(e && e[0] == 'g')) return launch_sc_static(c, llr, info_hat, B);  // "generic": keep the generic kernel
-    }
+    if (dispatch_sc(c, dtype, nullptr, nullptr, flags) == KF_SC_STATIC) return launch_sc_static(c, llr, info_hat, B);
     if (dtype != POLAR_F32) {
         polar_set_error("register SC kernel: fp32 only");
         return POLAR_EUNSUPPORTED;

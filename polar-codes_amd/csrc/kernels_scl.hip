@@ -468,8 +468,15 @@ int launch_scl_decode(polar_code *c, const void *llr, int dtype, int L, uint32_t
         polar_set_error("SCL decoder: N=%d exceeds the supported maximum of 4096", c->N);
         return POLAR_EUNSUPPORTED;
     }
-    if (scl_reg_supported(c, dtype, L, pm, u_hat_all)) return launch_scl_reg(c, llr, dtype, info_hat, pm, u_hat_all, B, crc, truth, L);
-    if (scl_wide_supported(c, dtype, L, pm, u_hat_all)) return launch_scl_wide(c, llr, dtype, info_hat, pm, u_hat_all, B, L, crc, truth);
-    if (dtype == POLAR_F32) return launch_scl_l<float>(c, llr, L, info_hat, pm, u_hat_all, B, crc, truth);
-    return launch_scl_l<double>(c, llr, L, info_hat, pm, u_hat_all, B, crc, truth);
+    switch (dispatch_scl(c, dtype, L, pm, u_hat_all)) {
+    case KF_SCL_REG: return launch_scl_reg(c, llr, dtype, info_hat, pm, u_hat_all, B, crc, truth, L);
+    case KF_SCL_WIDE: return launch_scl_wide(c, llr, dtype, info_hat, pm, u_hat_all, B, L, crc, truth);
+    case KF_SCL_LDS:
+        if (dtype == POLAR_F32) return launch_scl_l<float>(c, llr, L, info_hat, pm, u_hat_all, B, crc, truth);
+        return launch_scl_l<double>(c, llr, L, info_hat, pm, u_hat_all, B, crc, truth);
+    default:
+        polar_set_error("list decoder: no kernel serves N=%d, K=%d, L=%d, %s (polar_dispatch_table lists what is served)", c->N, c->K, L,
+                        dtype == POLAR_F32 ? "fp32" : "fp64");
+        return POLAR_EUNSUPPORTED;
+    }
 }

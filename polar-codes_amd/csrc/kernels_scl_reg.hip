@@ -1077,13 +1077,7 @@ extern "C" __attribute__((visibility("default"))) int polar_debug_scl_profile(un
 // ------------------------------------------------------------------------------------------ host side
 bool scl_reg_supported(const polar_code *c, int dtype, int L, const void *pm, const void *u_hat_all)
 {
-    if (L != 8 && L != 4 && L != 2) return false;
-    // fp32 list outputs (metrics, every path) stay with the LDS-staged kernel
-    if (dtype == POLAR_F32 ? (pm || u_hat_all) : dtype != POLAR_F64) return false;
-    if (c->n < 6 || c->n > 10 || c->K < 3) return false;
-    const char *e = polar_switch("POLAR_SCL_KERNEL");
-    if (e && e[0] == 'l') return false;  // "lds": force the LDS-staged kernel
-    return true;
+    return dispatch_scl(c, dtype, L, pm, u_hat_all) == KF_SCL_REG;  // the table of host_tables.cpp says what this kernel serves
 }
 
 template <int NLOG, int LMAX, typename T>

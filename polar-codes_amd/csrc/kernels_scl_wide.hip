@@ -650,13 +650,7 @@ int launch_wide_l(polar_code *c, const void *llr, int dtype, uint32_t *info_hat,
 
 bool scl_wide_supported(const polar_code *c, int dtype, int L, const void *pm, const void *u_hat_all)
 {
-    if ((dtype != POLAR_F32 && dtype != POLAR_F64) || (L != 16 && L != 32)) return false;
-    // fp32 list outputs (metrics, every path) stay with the LDS-staged kernel, like the eight-lanes-per-path kernel's
-    if (dtype == POLAR_F32 && (pm || u_hat_all)) return false;
-    if (c->n < 6 || c->n > 10 || c->K < 5) return false;
-    const char *e = polar_switch("POLAR_SCL_KERNEL");
-    if (e && e[0] == 'l') return false;  // "lds": force the LDS-staged kernel
-    return true;
+    return dispatch_scl(c, dtype, L, pm, u_hat_all) == KF_SCL_WIDE;  // the table of host_tables.cpp says what this kernel serves
 }
 
 int launch_scl_wide(polar_code *c, const void *llr, int dtype, uint32_t *info_hat, double *pm, uint32_t *u_hat_all, int64_t B, int L,

@@ -973,6 +973,43 @@ extern "C" int polar_sc_decode_flip(polar_code *c, const void *llr, int dtype, c
     return POLAR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- dispatch table
+// No GPU is needed for these two: they read the static table of host_tables.cpp.
+extern "C" int polar_dispatch_select(int op, int N, int K, int dtype, int L, int outputs, int flags, char *kernel, int kernel_len)
+{
+    ARG_TRY(N >= 1 && (N & (N - 1)) == 0, "N must be a power of two");
+    int n = 0;
+    while ((1 << n) < N) n++;
+    const DispatchQuery q{op, n, K, dtype == POLAR_F32 ? 0 : dtype == POLAR_F64 ? 1 : -1, L, outputs, flags};
+    const int row = dispatch_select(q);
+    if (row < 0) {
+        polar_set_error("no kernel serves this call (op %d, N=%d, K=%d, dtype %d, L=%d, outputs 0x%x, flags 0x%x)", op, N, K, dtype, L, outputs, flags);
+        return POLAR_EUNSUPPORTED;
+    }
+    if (kernel && kernel_len > 0) snprintf(kernel, (size_t)kernel_len, "%s", dispatch_table(nullptr)[row].kernel);
+    return row;
+}
+
+extern "C" int polar_dispatch_table(char *buf, int len)
+{
+    int count = 0;
+    const DispatchRow *t = dispatch_table(&count);
+    std::string out = "row\top\tkernel\tdtypes\tlog2N\tL\tK>=\toutputs\tone_of\tneed\tforbid\twhat\n";
+    static const char *ops[] = {"SC", "SCL", "PBF", "MC_SC"};
+    char line[512];
+    for (int i = 0; i < count; i++) {
+        std::string ls;
+        for (int l = 1; l <= 32; l++)
+            if ((t[i].l_mask >> (l - 1)) & 1u) ls += (ls.empty() ? "" : ",") + std::to_string(l);
+        snprintf(line, sizeof(line), "%d\t%s\t%s\t%s%s\t%d..%d\t%s\t%d\t0x%x\t0x%x\t0x%x\t0x%x\t%s\n", i, ops[t[i].op], t[i].kernel,
+                 (t[i].dtypes & 1u) ? "f32" : "", (t[i].dtypes & 2u) ? ((t[i].dtypes & 1u) ? ",f64" : "f64") : "", t[i].n_min, t[i].n_max,
+                 ls.empty() ? "-" : ls.c_str(), t[i].k_min, t[i].outputs_ok, t[i].outputs_any, t[i].need, t[i].forbid, t[i].what);
+        out += line;
+    }
+    if (buf && len > 0) snprintf(buf, (size_t)len, "%s", out.c_str());
+    return (int)out.size() + 1;  // bytes a complete copy needs
+}
+
 // ---------------------------------------------------------------------------------------------- counting / MC
 extern "C" int polar_count_errors(polar_code *c, const uint32_t *info, const uint32_t *hat, int64_t B, int flags,
                                   uint64_t *counters)
@@ -1055,9 +1092,11 @@ extern "C" int polar_mc_run(polar_code *c, int decoder, int L, int dtype, int fl
     const size_t es = llr_size(dtype);
     // a code with a specialised decoder runs fp32 SC frames in one kernel, from the random bits to the counters, with no
     // LLR buffer at all (POLAR_MC_KERNEL=staged keeps the generator -> buffer -> decoder pipeline below)
-    if (decoder == POLAR_DEC_SC && dtype == POLAR_F32 && (flags & POLAR_SC_FAST) && !crc && c->static_mc_fn) {
-        const char *e = polar_switch("POLAR_MC_KERNEL");
-        if (!(e && e[0] == 's')) {
+    if (decoder == POLAR_DEC_SC && c->static_mc_fn) {
+        const DispatchQuery q{DQ_OP_MC_SC, c->n, c->K, dtype == POLAR_F32 ? 0 : 1, 0, 0,
+                              ((flags & POLAR_SC_FAST) ? DQ_FAST : 0) | DQ_SPECIALISED | (crc ? DQ_CRC : 0) | dq_switch_flags("POLAR_MC_KERNEL")};
+        const int row = dispatch_select(q);
+        if (row >= 0 && dispatch_table(nullptr)[row].family == KF_MC_FUSED) {
             int rc;
             if ((rc = ctx->counters.reserve(3 * sizeof(uint64_t)))) return rc;
             uint64_t *dcnt = ctx->counters.as<uint64_t>();

@@ -160,6 +160,30 @@ inline const char *polar_switch(const char *name)
     return getenv(name);
 }
 
+// ---- dispatch: every launcher asks the table of host_tables.cpp which kernel family serves the call ---------------------
+inline int dq_switch_flags(const char *var)
+{
+    const char *e = polar_switch(var);
+    if (!e) return 0;
+    return e[0] == 'l' ? DQ_FORCE_LDS : (e[0] == 'g' || e[0] == 's') ? DQ_FORCE_GENERIC : 0;
+}
+// family (KernelFamily) that serves an SC call on this code, or -1
+inline int dispatch_sc(const polar_code *c, int dtype, const void *u_hat, const void *dec_llr, int flags)
+{
+    DispatchQuery q{DQ_OP_SC, c->n, c->K, dtype == POLAR_F32 ? 0 : dtype == POLAR_F64 ? 1 : -1, 0,
+                    DQ_OUT_INFO | (u_hat ? DQ_OUT_UHAT : 0) | (dec_llr ? DQ_OUT_DECLLR : 0),
+                    ((flags & POLAR_SC_FAST) ? DQ_FAST : 0) | (c->static_fn ? DQ_SPECIALISED : 0) | dq_switch_flags("POLAR_SC_KERNEL")};
+    const int row = dispatch_select(q);
+    return row < 0 ? -1 : dispatch_table(nullptr)[row].family;
+}
+inline int dispatch_scl(const polar_code *c, int dtype, int L, const void *pm, const void *u_hat_all)
+{
+    DispatchQuery q{DQ_OP_SCL, c->n, c->K, dtype == POLAR_F32 ? 0 : dtype == POLAR_F64 ? 1 : -1, L,
+                    DQ_OUT_INFO | (u_hat_all ? DQ_OUT_UHAT : 0) | (pm ? DQ_OUT_PM : 0), dq_switch_flags("POLAR_SCL_KERNEL")};
+    const int row = dispatch_select(q);
+    return row < 0 ? -1 : dispatch_table(nullptr)[row].family;
+}
+
 // Failure injection for the tests of the error paths (POLAR_FAULT_AT=<site>, honoured like every switch only with
 // POLAR_EXPERIMENT=1): the named site behaves as if its runtime call had failed.
 inline bool polar_fault_at(const char *site)

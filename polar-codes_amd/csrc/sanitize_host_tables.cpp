@@ -42,6 +42,23 @@ int main()
             }
         }
     }
+    // the dispatch table: every query in and around its ranges selects a row of the table or none
+    int rows = 0;
+    const DispatchRow *tab = dispatch_table(&rows);
+    for (int op = -1; op <= 4; op++)
+        for (int n = -1; n <= 18; n++)
+            for (int dt = -1; dt <= 2; dt++)
+                for (int L : {-1, 0, 1, 2, 3, 8, 16, 32, 33, 64})
+                    for (int outputs : {0, 1, 3, 7, 9, 15, 255})
+                        for (int flags : {0, 1, 3, 7, 64, 128, 511}) {
+                            const int N = n >= 0 ? 1 << n : 0;
+                            for (int K : {-1, 0, 1, N / 2, N}) {
+                                const int r = dispatch_select(DispatchQuery{op, n, K, dt, L, outputs, flags});
+                                if (r < -1 || r >= rows) return 1;
+                                if (r >= 0 && tab[r].op != op) return 1;
+                                total += (size_t)(r + 1);
+                            }
+                        }
     printf("host tables sanitizer run ok (%zu)\n", total);
     return 0;
 }

@@ -97,25 +97,41 @@ def test_scl_metric_overflow_gives_minus_inf():
     np.testing.assert_allclose(pm[0][np.isfinite(rpm)], rpm[np.isfinite(rpm)], rtol=1e-12)
 
 
-def test_scl_fp32_mode_vs_fp32_oracle():
-    """fp32 arithmetic: same algorithm as the fp32 oracle; device exp2f/log2f differ from the host's in
-    the last bits, so only near-tied metrics may order differently: at least 97 % of frames must give
-    identical decoded bits and the frame error counts must agree within 3."""
+def test_scl_fp32_mode_vs_fp32_oracle(monkeypatch):
+    """fp32 arithmetic at a short length, (256,128) L = 8, held to the fp32 oracle frame by frame with the margin argument of
+    test_scl8_headline_kernel_vs_fp32_oracle: device and host differ only in exp2 / log2 of the branch metric; that
+    difference is measured on the lists the LDS-staged kernel returns, and every frame whose closest pair of competing
+    metrics (reported by the oracle) lies further apart than twice that difference must decode to the oracle's bits, on
+    the register kernel and on the LDS-staged kernel alike."""
     N, K, L = 256, 128, 8
     mask = pcf.degaBuild(N, K, 2.0)
     code = _native.Code(_native.default_ctx(), mask)
-    frames = [make_frame(mask, 1.5, 4000 + s, oracle.polar_encode) for s in range(120)]
+    frames = [make_frame(mask, 1.5, 4000 + s, oracle.polar_encode) for s in range(400)]
     llr = np.stack([f[2] for f in frames]).astype(np.float32)
-    info, _, _ = code.scl_decode(llr, L)
-    same, fe_gpu, fe_cpu = 0, 0, 0
-    for b, fr in enumerate(frames):
-        ruh, _, _ = oracle.scl_decode(llr[b], mask, L)
-        ref = oracle.extract(ruh[0], mask)
-        same += np.array_equal(info[b], ref)
-        fe_gpu += np.any(info[b] != fr[0])
-        fe_cpu += np.any(ref != fr[0])
-    assert same >= 0.97 * len(frames), same
-    assert abs(int(fe_gpu) - int(fe_cpu)) <= 3
+    B = len(frames)
+    monkeypatch.delenv("POLAR_SCL_KERNEL", raising=False)
+    got, _, _ = code.scl_decode(llr, L)
+    assert code.last_launch()["kernel"].startswith("scl_reg_kernel<8>/L8"), code.last_launch()
+    monkeypatch.setenv("POLAR_SCL_KERNEL", "lds")
+    lds, pm, uh = code.scl_decode(llr, L, want_list=True)
+    assert np.array_equal(got, lds)
+    ref = np.empty_like(got)
+    gap = np.empty(B)
+    err = 0.0
+    for b in range(B):
+        ruh, rpm, _ = oracle.scl_decode(llr[b], mask, L)
+        gap[b] = oracle.scl_last_min_gap()
+        ref[b] = oracle.extract(ruh[0], mask)
+        if np.array_equal(uh[b], ruh):
+            fin = np.isfinite(rpm)
+            assert np.array_equal(np.isfinite(pm[b]), fin)
+            err = max(err, float(np.max(np.abs(pm[b][fin] - rpm[fin]) / np.maximum(np.abs(rpm[fin]), 1.0), initial=0.0)))
+    margin = 2.0 * err
+    same = np.all(got == ref, axis=1)
+    inside = gap <= margin
+    assert err < 1e-5
+    assert same[~inside].all(), np.flatnonzero(~same & ~inside)[:10]
+    assert (~same).sum() <= 0.02 * B
 
 
 def test_scl_list_1_equals_sc_and_L_improves_fer():
