@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(64) scl_decode_kernel(SCLParams<T> p, const ui
                     const T cpm_a = pm + (T)1;
                     const T next = shfl_real(cpm_a, lane + G < 64 ? lane + G : lane);  // the agreeing extension of the next list position
                     const T last = bcast_real(cpm_a, (L - 1) * G);
-                    const bool sure = big && pm + ((T)2 - ae_lo) < last && (grp == L - 1 || cpm_a > next);
+                    const bool sure = (bool)((int)big & (int)(pm + ((T)2 - ae_lo) < last) & ((int)(grp == L - 1) | (int)(cpm_a > next)));
                     if (__ballot(sure) == ~0ull) {
                         pm = cpm_a;
                         bit = v < (T)0 ? 1u : 0u;

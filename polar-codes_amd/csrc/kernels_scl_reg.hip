@@ -6,13 +6,15 @@
 // exchanges are the DPP patterns row_half_mirror, quad_perm[2,3,0,1], quad_perm[1,0,3,2]).  Levels of
 // width >= 16 are per-lane register arithmetic on a slice of N/8 values; partial sums are bit slices.
 //
-// Forking never copies a slice.  Every path keeps, in two 32-bit registers, the list position ("owner")
-// whose registers hold each of its LLR levels and each of its left-child partial-sum levels.  All paths
-// rewrite a level in lockstep, each into its own registers, so an owner's registers stay valid until
-// every path has replaced that level.  Right-child g operations and combines fetch their operands from
-// the owner's lanes with ds_bpermute (or, for a level kept in memory, from the owner's lanes' slots); a fork or
-// prune only moves the small per-path state (metric, owner rows, the live values and bits of the 8-leaf subtree
-// being decoded).
+// Forking never copies a wide slice.  Every path keeps, in one 32-bit register, the list position ("owner")
+// whose registers hold each of its LLR levels of 32 elements and more and each of its left-child partial-sum levels
+// of 256 bits and more.  All paths rewrite a level in lockstep, each into its own registers, so an owner's registers
+// stay valid until every path has replaced that level.  Right-child g operations and combines of those levels fetch
+// their operands from the owner's lanes with ds_bpermute (or, for a level kept in memory, from the owner's lanes'
+// slots).  What is narrow travels with the path instead: a fork or prune moves the metric, the owner row, the live
+// values and bits of the 8-leaf subtree being decoded, the two LLRs per lane of the enclosing 16-leaf node and the
+// one word that holds the left-child partial sums of every node up to 128 leaves -- so the narrow levels, which are
+// walked most often (64 nodes of 16 leaves per 1024), run on a lane's own registers without any fetch or owner entry.
 //
 // Path metric and ordering follow the reference's sclDecoder / polarSCLFork: PM += 1 - log2(1 + 2^(-+Li));
 // below saturation list = originals ++ copies; at saturation the 16 candidates, ordered copies(u=1) ++
@@ -131,13 +133,19 @@ constexpr int SCL_SLAB_SLOTS = 8192;  // slabs for the level in global memory: a
 // Small per-path state that moves between lane groups at a fork.
 template <typename T> struct PathState {
     T pm;
-    uint32_t ownL;   // 3 bits per level l (index l - 3): position whose registers hold my level-l LLRs; bits 24..26: see XB
-    uint32_t ownP;   // same for the left-child partial sums of level l
+    uint32_t ownL;   // 3 bits per level l (index l - 3) for l >= 5: position whose registers hold my level-l LLRs; bits 24..26: see XB;
+                     // bits OPB8.. / OPB9..: position that holds my left-child partial sums of level 8 / 9 (the narrower ones travel)
     T v[3];          // my element of the LLRs of the enclosing 8-, 4- and 2-leaf nodes, until their g has run
     // bit XB + I of ownL: partial-sum bit of the finished left child of the enclosing node I (one word less to move at a fork)
 };
 
 constexpr int XB = 24;
+constexpr int OPB8 = 21, OPB9 = 27;  // bit positions in ownL of the partial-sum owners of levels 8 and 9
+constexpr int EAGER_P_TOP = 7;       // left-child partial sums of levels 3 .. 7 (bits 1 .. 31 of a0) travel with the path
+#ifndef POLAR_SCL_EAGER_L_TOP
+#define POLAR_SCL_EAGER_L_TOP 3
+#endif
+constexpr int EAGER_L_TOP = POLAR_SCL_EAGER_L_TOP;  // so do the LLRs of levels 3 (as v[0]) and, with 4, of level 4
 
 // Largest subtrees (log2 of their leaves) decoded as one unit: all-frozen ones, and all-information ones every path is sure
 // of.  The register allocation of the N = 1024 kernel sits at its limit of 128; larger units (up to 6 is written) spill.
@@ -184,10 +192,8 @@ struct LaneConst {
     uint32_t lowmask[3];
     // ranking of the 16 candidates of a saturated list: my candidate is (p, u = q >> 2); quad lane k = q & 3 compares
     // it with candidates (2k, 0), (2k, 1), (2k+1, 0), (2k+1, 1)
-    int rsrc[4];         // byte address (lane * 4) of a lane that holds the other candidate's metric
+    int rsrc0;           // byte address (lane * 4) of the lane that holds the first of those four metrics; the others follow 16 bytes apart
     uint32_t rsub[4];    // 1 if the other candidate precedes mine in the candidate order copies(u=1) ++ originals(u=0)
-    uint32_t keepflip;   // 1 for the lanes that evaluate u = 0
-    uint32_t ubit[2];    // bit 31 = the u of my own / of my path's other candidate
 };
 
 // At N = 1024 a path's slice is 128 LLRs per lane; with all of them in registers two wavefronts fit on a SIMD, and the
@@ -292,6 +298,13 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
     {
         return (row & ~(7u << (3 * (lev - 3)))) | (p << (3 * (lev - 3)));
     }
+    // owner of the left-child partial sums of level lev (8 or 9: the narrower levels are the lane's own)
+    static __device__ __forceinline__ uint32_t ownp_get(uint32_t row, int lev) { return (row >> (lev == 8 ? OPB8 : OPB9)) & 7u; }
+    static __device__ __forceinline__ uint32_t ownp_set(uint32_t row, int lev, uint32_t p)
+    {
+        const int sh = lev == 8 ? OPB8 : OPB9;
+        return (row & ~(7u << sh)) | (p << sh);
+    }
 
     // Both steps read their operands in batches of up to 16 pairs before the first result of the batch is stored: loads
     // that follow a store to memory the compiler cannot tell apart would otherwise wait for it one by one (64 dependent
@@ -323,22 +336,26 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
             if constexpr (MEM && sizeof(T) == 8) __builtin_amdgcn_sched_barrier(0);  // one batch of operands in registers at a time
         }
         level_written<LEV - 1>();
-        st.ownL = own_set(st.ownL, LEV - 1, (uint32_t)lc.p);
+        if constexpr (LEV - 1 > EAGER_L_TOP) st.ownL = own_set(st.ownL, LEV - 1, (uint32_t)lc.p);
     }
-    // g: operands and the left child's partial sums come from their owners' lanes
+    // g: operands and the left child's partial sums come from their owners' lanes (levels that travel with the path: from mine)
     template <int LEV> __device__ __forceinline__ void step_g(const T *chan_lane, const LaneConst &lc)
     {
         constexpr int c = 1 << (LEV - 4);
         constexpr bool MEM = LEV == NLOG || LEV >= St::GLOBAL_MIN || LEV == St::LDS_LEVEL;
         constexpr int BT = MEM ? (c < BATCH ? c : BATCH) : (c < 4 ? c : 4);  // register levels: four pairs of lane gathers in flight
-        const int srcP = (int)own_get(st.ownP, LEV - 1) * 8 + lc.q;
-        const int srcL = opaque((LEV == NLOG) ? 0 : (int)own_get(st.ownL, LEV) * 8 + lc.q);
+        constexpr bool OWN_L = LEV <= EAGER_L_TOP && LEV != NLOG;  // the operands are in my own registers
+        const int srcL = opaque((LEV == NLOG || OWN_L) ? 0 : (int)own_get(st.ownL, LEV) * 8 + lc.q);
         const int lq = opaque(my_lane);
         if constexpr (LEV == NLOG) chan_lane = opaque(chan_lane);
         uint64_t bits;
-        if constexpr (c == 64) bits = bperm_u64(a1, srcP);
-        else if constexpr (c >= 16) bits = (bperm_u64(a0, srcP) >> c) & (((uint64_t)1 << c) - 1);
-        else bits = (uint64_t)((bperm_u((uint32_t)a0, srcP) >> c) & ((1u << c) - 1u));
+        if constexpr (LEV - 1 <= EAGER_P_TOP) {
+            bits = (uint64_t)(((uint32_t)a0 >> c) & ((1u << c) - 1u));
+        } else {
+            const int srcP = (int)ownp_get(st.ownL, LEV - 1) * 8 + lc.q;
+            if constexpr (c == 64) bits = bperm_u64(a1, srcP);
+            else bits = (uint64_t)bperm_u((uint32_t)(a0 >> 32), srcP);
+        }
         // operands are level LEV, results level LEV-1: no lane overwrites what another still reads
 #pragma unroll
         for (int j0 = 0; j0 < c; j0 += BT) {
@@ -348,6 +365,9 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
                 if constexpr (LEV == NLOG) {
                     a[t] = chan_lane[8 * (j0 + t)];
                     b[t] = chan_lane[8 * (j0 + t + c)];
+                } else if constexpr (OWN_L) {
+                    a[t] = ld_own<LEV>(j0 + t, lq);
+                    b[t] = ld_own<LEV>(c + j0 + t, lq);
                 } else {
                     a[t] = ld_from<LEV>(j0 + t, srcL);
                     b[t] = ld_from<LEV>(c + j0 + t, srcL);
@@ -358,16 +378,19 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
             if constexpr (MEM && sizeof(T) == 8) __builtin_amdgcn_sched_barrier(0);  // one batch of operands in registers at a time
         }
         level_written<LEV - 1>();
-        st.ownL = own_set(st.ownL, LEV - 1, (uint32_t)lc.p);
+        if constexpr (LEV - 1 > EAGER_L_TOP) st.ownL = own_set(st.ownL, LEV - 1, (uint32_t)lc.p);
     }
     template <int LEV> __device__ __forceinline__ void combine(int plane, const LaneConst &lc)
     {
         constexpr int c = 1 << (LEV - 4);  // bits per lane of each child
-        const int srcP = (int)own_get(st.ownP, LEV - 1) * 8 + lc.q;
         uint64_t xl;
-        if constexpr (c == 64) xl = bperm_u64(a1, srcP);
-        else if constexpr (c >= 16) xl = (bperm_u64(a0, srcP) >> c) & (((uint64_t)1 << c) - 1);
-        else xl = (uint64_t)((bperm_u((uint32_t)a0, srcP) >> c) & ((1u << c) - 1u));
+        if constexpr (LEV - 1 <= EAGER_P_TOP) {
+            xl = (uint64_t)(((uint32_t)a0 >> c) & ((1u << c) - 1u));
+        } else {
+            const int srcP = (int)ownp_get(st.ownL, LEV - 1) * 8 + lc.q;
+            if constexpr (c == 64) xl = bperm_u64(a1, srcP);
+            else xl = (uint64_t)bperm_u((uint32_t)(a0 >> 32), srcP);
+        }
         const uint64_t xr = get_bits<c>(b0, b1);
         if constexpr (LEV == NLOG) {
             if constexpr (c == 64) {
@@ -383,7 +406,7 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
                 set_bits<2 * c>(b0, b1, x);
             } else {
                 set_bits<2 * c>(a0, a1, x);
-                st.ownP = own_set(st.ownP, LEV, (uint32_t)lc.p);
+                if constexpr (LEV > EAGER_P_TOP) st.ownL = ownp_set(st.ownL, LEV, (uint32_t)lc.p);
             }
         }
     }
@@ -395,7 +418,11 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
         const int src = par * 8 + lc.q;
         st.pm = bperm_f(cpm, par * 8 + 4 * (int)b + (lc.q & 3));  // lanes q >= 4 hold the u=1 candidate metric
         st.ownL = bperm_u(st.ownL, src);
-        st.ownP = bperm_u(st.ownP, src);
+        a0 = (a0 & 0xFFFFFFFF00000000ull) | bperm_u((uint32_t)a0, src);
+        if constexpr (EAGER_L_TOP >= 4) {
+            R[2] = bperm_f(R[2], src);
+            R[3] = bperm_f(R[3], src);
+        }
 #pragma unroll
         for (int i = 0; i < 3; i++)
             if ((LIVE >> i) & 1u) st.v[i] = bperm_f(st.v[i], src);
@@ -468,7 +495,9 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
             const T next = bperm_f(cpm_a, lc.lane + 8);  // the agreeing extension of the next list position
             const T other = st.pm + ((T)2 - ae_lo);
             const T last = lane_value(cpm_a, 8 * (LMAX - 1));
-            const bool sure = big && other < last && (lc.p == LMAX - 1 || cpm_a > next);
+            // the three conditions as one expression without short-circuit evaluation: as nested branches on the lanes' own
+            // outcomes (what && compiles to) the test cost 4 % of the kernel's time
+            const bool sure = (bool)((int)big & (int)(other < last) & ((int)(lc.p == LMAX - 1) | (int)(cpm_a > next)));
 #ifdef POLAR_SCL_PROFILE
             {   // why a leaf goes on to the ranking: some LLR small (1), else another extension could survive (2), else order (3)
                 const bool dead = LMAX < 8 && lc.p >= LMAX;
@@ -491,7 +520,7 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
         const auto key = order_key(rpm);
         decltype(order_key(rpm)) o[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) o[i] = bperm_key(key, lc.rsrc[i]);
+        for (int i = 0; i < 4; i++) o[i] = bperm_key(key, lc.rsrc0 + 16 * i);
         int cnt = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) cnt += (o[i] > key - lc.rsub[i]) ? 1 : 0;
@@ -505,7 +534,7 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
         if (((km | (km >> 4)) & EVERY) == EVERY) {
             PROF_COUNT(23);
             st.pm = keep ? cpm : cpm_o;
-            return (keep ? 1u : 0u) ^ lc.keepflip;  // u = 1 survived iff the u = 1 lanes keep / the u = 0 lanes do not
+            return (keep ? 1u : 0u) ^ (bme ^ 1u);  // u = 1 survived iff the u = 1 lanes keep / the u = 0 lanes do not
         }
         const int cnt_o = (int)dpp_mov_u32<0x141>((uint32_t)cnt);  // the rank of my path's other candidate
         const int rk[2] = {cnt, cnt_o};
@@ -515,12 +544,16 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
             if (rk[u] < Lmax) {
                 uint32_t *rec = xch + rk[u] * 8 + lc.q;
                 rec[0] = st.ownL;
-                rec[64] = st.ownP | lc.ubit[u];
+                rec[64] = ((uint32_t)a0 & ~1u) | (bme ^ (uint32_t)u);  // bit 0 of a0 belongs to no level; u = 0: my own candidate
                 int w = 2;
                 rec_put(rec, w, mt[u]);
 #pragma unroll
                 for (int i = 0; i < 3; i++)
                     if ((LIVE >> i) & 1u) rec_put(rec, w, st.v[i]);
+                if constexpr (EAGER_L_TOP >= 4) {
+                    rec_put(rec, w, R[2]);
+                    rec_put(rec, w, R[3]);
+                }
             }
         }
         wave_sync();
@@ -533,10 +566,14 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
 #pragma unroll
             for (int i = 0; i < 3; i++)
                 if ((LIVE >> i) & 1u) rec_get(mine, w, st.v[i]);
+            if constexpr (EAGER_L_TOP >= 4) {
+                rec_get(mine, w, R[2]);
+                rec_get(mine, w, R[3]);
+            }
         }
         wave_sync();
-        st.ownP = op & 0x7FFFFFFFu;
-        return op >> 31;
+        a0 = (a0 & 0xFFFFFFFF00000000ull) | (op & ~1u);
+        return op & 1u;
     }
 
     // A node of P leaves (2, 4 or 8), all frozen: nothing forks and every partial sum is zero, so the P decision LLRs
@@ -576,9 +613,9 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
         if (plane) {
             set_bits<CB>(b0, b1, x);
         } else {
-            set_bits<CB>(a0, a1, x);
-            st.ownP = own_set(st.ownP, LV, (uint32_t)lc.p);
+            set_bits<CB>(a0, a1, x);  // LV <= 6: these sums travel with the path, no owner entry
         }
+        (void)lc;
     }
     // All 2^LV leaves frozen: every decision is 0, so nothing forks, no owner changes and no partial sum is ever non-zero:
     // g is hi + lo everywhere.  The decision LLRs of all leaves are computed side by side (register j of the lane ends as
@@ -648,7 +685,8 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
         const T pm = st.pm;
         const T next = bperm_f(pm, lc.lane + 8);
         const T last = lane_value(pm, 8 * (LMAX - 1));
-        const bool ok = big && fabs_t(pm) < (T)4000 && pm + ((T)2 - ae) + DELTA < last + (T)1 && (lc.p == LMAX - 1 || pm - next > DELTA);
+        const bool ok = (bool)((int)big & (int)(fabs_t(pm) < (T)4000) & (int)(pm + ((T)2 - ae) + DELTA < last + (T)1) &
+                               ((int)(lc.p == LMAX - 1) | (int)(pm - next > DELTA)));  // no short-circuit: see leaf_sat
         PROF_COUNT(24 + 2 * (LV - 3));
 #ifdef POLAR_SCL_PROFILE
         if (LV == 3) {  // why not: smallest LLR too small (32), metric out of range (33), another extension could survive (34), order (35)
@@ -798,7 +836,6 @@ __device__ __forceinline__ void scl_node(SclReg<NLOG, LMAX, T> &d, uint32_t mask
                 d.b0 = (d.b0 & ~(uint64_t)2) | ((uint64_t)x << 1);
             } else {
                 d.a0 = (d.a0 & ~(uint64_t)2) | ((uint64_t)x << 1);
-                d.st.ownP = SclReg<NLOG, LMAX, T>::own_set(d.st.ownP, 3, (uint32_t)lc.p);
             }
         } else {
             if constexpr (LEV - 1 <= 6 && (LEV - 1 <= POLAR_SCL_FROZEN_TOP || LEV - 1 <= POLAR_SCL_SURE_TOP)) {
@@ -836,10 +873,10 @@ scl_reg_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, co
                int Kw, void *__restrict__ slab, double *__restrict__ pm_out, uint32_t *__restrict__ u_hat_all, uint32_t slot_words,
                uint32_t *__restrict__ fault)
 {
-    // exchange records of the pruning step (6 words per lane in fp32, 10 in fp64, word-major); its first words double as the
+    // exchange records of the pruning step (8 words per lane in fp32, 14 in fp64, word-major); its first words double as the
     // survivor table of the general leaf, and the whole area as the staging buffer of the output stage (8 paths x 8 lanes x
     // 128-bit slice of u_hat)
-    constexpr int XW = 2 + 4 * (int)(sizeof(T) / 4);
+    constexpr int XW = 2 + (EAGER_L_TOP >= 4 ? 6 : 4) * (int)(sizeof(T) / 4);
     __shared__ uint32_t xchg[64 * XW];
     uint32_t *const surv = xchg;
     uint32_t *const stage = xchg;
@@ -870,14 +907,11 @@ scl_reg_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, co
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int op = 2 * k + (i >> 1), ob = i & 1;
-            lc.rsrc[i] = (op * 8 + 4 * ob) << 2;
+            if (i == 0) lc.rsrc0 = (op * 8 + 4 * ob) << 2;  // candidate i sits 4 lanes (16 bytes) further: (2k + i / 2) * 8 + 4 (i & 1)
             // candidates of empty positions (list sizes below 8) come after every real one
             const int opos = (ob ? op : 8 + op) + ((LMAX == 8 || op < LMAX) ? 0 : 16);
             lc.rsub[i] = opos < cpos + ((LMAX == 8 || lc.p < LMAX) ? 0 : 16) ? 1u : 0u;
         }
-        lc.keepflip = bme ? 0u : 1u;
-        lc.ubit[0] = (uint32_t)bme << 31;
-        lc.ubit[1] = (uint32_t)(1 - bme) << 31;
     }
     const uint32_t maskv = maskw[(lc.lane & 31) < (N / 32) ? (lc.lane & 31) : 0];
     SclReg<NLOG, LMAX, T> d;
@@ -924,7 +958,7 @@ scl_reg_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, co
         const T *chan_lane = llr + f * N + lc.e;
         d.a0 = d.a1 = d.b0 = d.b1 = d.r0 = d.r1 = 0;
         d.st.pm = (T)0;
-        d.st.ownL = d.st.ownP = 0u;
+        d.st.ownL = 0u;
 #pragma unroll
         for (int i = 0; i < 3; i++) d.st.v[i] = (T)0;
         d.Lcur = 1;
@@ -1122,7 +1156,7 @@ static int launch_scl_reg_t(polar_code *c, const void *llr, uint32_t *info_hat, 
     if (sizeof(T) == 4) snprintf(c->last.kernel, sizeof(c->last.kernel), "scl_reg_kernel<%d>/L%d", NLOG, LMAX);
     else snprintf(c->last.kernel, sizeof(c->last.kernel), "scl_reg_kernel<%d,double>/L%d", NLOG, LMAX);
     c->last.lanes_per_frame = 64;
-    c->last.lds_bytes_per_block = 64 * 4 * (2 + 4 * (int)(sizeof(T) / 4)) + (NLOG < 10 ? 2 * c->N : 2) + (int)sizeof(T) * St::LDS_VALUES;
+    c->last.lds_bytes_per_block = 64 * 4 * (2 + (EAGER_L_TOP >= 4 ? 6 : 4) * (int)(sizeof(T) / 4)) + (NLOG < 10 ? 2 * c->N : 2) + (int)sizeof(T) * St::LDS_VALUES;
     c->last.block_threads = 64;
     c->last.grid_blocks = (int)grid;
     c->last.last_ms = ms;

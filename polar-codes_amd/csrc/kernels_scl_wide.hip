@@ -339,7 +339,8 @@ template <int NLOG, int LMAX, typename T> struct WideDec {
             const T next = wb_f(cpm_a, lane + 2);  // the agreeing extension of the next list position
             const T other = pm + ((T)2 - ae);
             const T last = lane_of(cpm_a, 2 * (LMAX - 1));
-            const bool sure = big && other < last && (p == LMAX - 1 || cpm_a > next);
+            // one expression without short-circuit evaluation (nested branches on the lanes' own outcomes are slower)
+            const bool sure = (bool)((int)big & (int)(other < last) & ((int)(p == LMAX - 1) | (int)(cpm_a > next)));
             if (__ballot(sure || (LMAX < 32 && p >= LMAX)) == ~0ull) {
                 pm = cpm_a;
                 return v < (T)0 ? 1u : 0u;

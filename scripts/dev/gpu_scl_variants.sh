@@ -27,6 +27,6 @@ for snr,nb in [(2.0,1<<19),(1.0,1<<17),(3.0,1<<17)]:
     ctx.sync()
     bad=int((ref!=hat[:nchk]).any(dim=1).sum().item())
     out.append('snr %.1f %.2f Mf/s (%.2f ms) differ %d/%d'%(snr,nb/(min(ms)*1e-3)/1e6,min(ms),bad,nchk))
-print(' | '.join(out), kern, k2, flush=True)
+print(' | '.join(out), kern, k2, 'grid', code.last_launch()['grid_blocks'], flush=True)
 PY
 done
