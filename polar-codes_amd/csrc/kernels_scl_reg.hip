@@ -128,6 +128,17 @@ __device__ __forceinline__ double fabs_t(double v) { return __builtin_fabs(v); }
 __device__ __forceinline__ float fmin_t(float a, float b) { return __builtin_fminf(a, b); }
 __device__ __forceinline__ double fmin_t(double a, double b) { return __builtin_fmin(a, b); }
 
+// up ? hi + lo : f(hi, lo) without control flow: both values are computed and one is selected (the compiler turns the
+// conditional expression around f's inline assembly into a branch on the lanes' own condition, which costs more than f)
+__device__ __forceinline__ float sum_or_f(bool up, float x, float o)
+{
+    const float s = x + o, f = f_fast(x, o);
+    float r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(s), "s"(__builtin_amdgcn_ballot_w64(up)));
+    return r;
+}
+__device__ __forceinline__ double sum_or_f(bool up, double x, double o) { return up ? x + o : f_fast(x, o); }
+
 constexpr int SCL_SLAB_SLOTS = 8192;  // slabs for the level in global memory: at least twice the resident workgroups
 
 // Small per-path state that moves between lane groups at a fork.
@@ -585,15 +596,15 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
         T x = v;
         if constexpr (P >= 8) {
             const T o = partner8<8>(x);
-            x = lc.up[0] ? x + o : f_fast(x, o);
+            x = sum_or_f(lc.up[0], x, o);
         }
         if constexpr (P >= 4) {
             const T o = partner8<4>(x);
-            x = lc.up[1] ? x + o : f_fast(x, o);
+            x = sum_or_f(lc.up[1], x, o);
         }
         {
             const T o = partner8<2>(x);
-            x = lc.up[2] ? x + o : f_fast(x, o);
+            x = sum_or_f(lc.up[2], x, o);
         }
         const T m = branch_metric_fast(x, 0u);
         T t[P];
@@ -640,11 +651,11 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
 #pragma unroll
         for (int j = 0; j < C; j++) {
             T o = partner8<8>(x[j]);
-            x[j] = lc.up[0] ? x[j] + o : f_fast(x[j], o);
+            x[j] = sum_or_f(lc.up[0], x[j], o);
             o = partner8<4>(x[j]);
-            x[j] = lc.up[1] ? x[j] + o : f_fast(x[j], o);
+            x[j] = sum_or_f(lc.up[1], x[j], o);
             o = partner8<2>(x[j]);
-            x[j] = lc.up[2] ? x[j] + o : f_fast(x[j], o);
+            x[j] = sum_or_f(lc.up[2], x[j], o);
             x[j] = branch_metric_fast(x[j], 0u);
         }
         T pm = st.pm;

@@ -6,10 +6,12 @@
 // Lane 2p + h belongs to list position p.  Element k of every tree level of a path lives in the lane with h = k & 1,
 // at index k >> 1, so the partners (k, k + half) of every f and g down to level 2 sit in one lane and are plain
 // register arithmetic; only the 2-leaf nodes exchange values between the two lanes of a path (one DPP swap).
-// Levels 1 .. 6 (63 values per lane) stay in registers, wider levels live lane-major in a slab of global memory
-// per wavefront (N = 512: levels 7 and 8, 48 KB, touched by twelve steps per frame; N = 1024: level 9 as well, 112 KB);
-// the channel LLRs, which every
-// path reads, are staged once per frame in LDS, split by parity.  Partial sums are bit slices in registers.
+// Levels 1 .. 6 (63 values per lane) stay in registers (level 6 in LDS from N = 256 on); the widest level below the
+// channel is stored nowhere: it is one f or g away from the channel LLRs, which every path reads and which are staged
+// once per frame in LDS, split by parity, so the two steps that consume it recompute their operands from there (with
+// the path's own partial sums of the root's left half, for the right half); the levels between (N = 512: level 7,
+// 16 KB per wavefront; N = 1024: levels 7 and 8, 48 KB) live lane-major in a slab of global memory per wavefront.
+// Partial sums are bit slices in registers.
 //
 // Forking never copies a slice: as in the 8-lanes-per-path kernel (kernels_scl_reg.hip) every path keeps rows of
 // 5-bit "owner" positions per level for its LLRs and its left-child partial sums, all paths rewrite a level in
@@ -92,13 +94,15 @@ template <int NLOG, typename T> struct WideStore {
     static constexpr int LDS_VALUES = SPLIT ? 32 * 64 : 1;       // values per wavefront
     static constexpr int REG_TOP = SPLIT ? 5 : (TOP < 6 ? TOP : 6);  // levels 1 .. REG_TOP in registers
     static constexpr int REG_VALUES = 1 << REG_TOP;              // level l: 2^(l-1) values at offset 2^(l-1)
+    static constexpr bool RECOMP = TOP >= 7;                     // level TOP is recomputed from the channel by its two consumers
+    static constexpr int MEM_TOP = RECOMP ? TOP - 1 : TOP;       // widest level kept in the slab
     static constexpr int mem_off(int l)                          // first slab row of level l (rows of 64 lanes)
     {
         int o = 0;
         for (int i = 7; i < l; i++) o += 1 << (i - 1);
         return o;
     }
-    static constexpr int MEM_ROWS = TOP >= 7 ? mem_off(TOP + 1) : 0;
+    static constexpr int MEM_ROWS = MEM_TOP >= 7 ? mem_off(MEM_TOP + 1) : 0;
 };
 
 template <int NLOG, int LMAX, typename T> struct WideDec {
@@ -118,6 +122,7 @@ template <int NLOG, int LMAX, typename T> struct WideDec {
     uint32_t oL[2], oP[2];  // owner rows, 5 bits per level: levels 1 .. 6 in word 0, from 7 on in word 1; oL[1] bit 31: see node2
     T x;                    // my element of the enclosing 2-leaf node's LLRs while its first leaf is decided
     int Lcur;
+    bool right;             // the walk is in the right half of the root (wave-uniform): level TOP is then g of the channel
 
     template <int LEV> static __device__ __forceinline__ uint32_t own_get(const uint32_t *row)
     {
@@ -233,24 +238,57 @@ template <int NLOG, int LMAX, typename T> struct WideDec {
     }
 
     // ---- f / g steps, level LEV -> LEV - 1 (2 <= LEV <= NLOG): c results per lane -------------------------------
+    // element j of level TOP, recomputed from the channel: f for the root's left half, g with the path's partial sums of the
+    // left half (tb) for the right half
+    template <bool RIGHT> __device__ __forceinline__ T top_val(int j, const Bits &tb) const
+    {
+        constexpr int ct = 1 << (NLOG - 2);
+        const T a = chs[j], b = chs[j + ct];
+        if constexpr (RIGHT) return g_fast(a, b, (uint32_t)(tb.w[j >> 6] >> (j & 63)) & 1u);
+        else return f_med(a, b);
+    }
     template <int LEV> __device__ __forceinline__ void step_f()
     {
         constexpr int c = 1 << (LEV - 2);
+        if constexpr (St::RECOMP && LEV == NLOG) {
+            right = false;  // level TOP is made where it is used
+            return;
+        }
+        constexpr bool FROM_TOP = St::RECOMP && LEV == St::TOP;
         constexpr bool MEM = LEV == NLOG || LEV >= 7 || LEV == St::LDS_LEVEL;
         constexpr int BMAX = sizeof(T) == 4 ? 16 : 8;  // pairs in flight: 32 registers of operands either way
         constexpr int BT = !MEM ? 1 : c < BMAX ? c : BMAX;
         const int lq = opaque(lane);
+        Bits tb{{0, 0, 0, 0}};
+        if constexpr (FROM_TOP)
+            if (right) tb = fetch_bits<(1 << (NLOG - 2))>((int)own_get<St::TOP>(oP) * 2 + h);
 #pragma unroll
         for (int j0 = 0; j0 < c; j0 += BT) {
             T a[BT], b[BT];
+            if constexpr (FROM_TOP) {
+                if (right) {
 #pragma unroll
-            for (int t = 0; t < BT; t++) {
-                if constexpr (LEV == NLOG) {
-                    a[t] = chs[j0 + t];
-                    b[t] = chs[j0 + t + c];
+                    for (int t = 0; t < BT; t++) {
+                        a[t] = top_val<true>(j0 + t, tb);
+                        b[t] = top_val<true>(c + j0 + t, tb);
+                    }
                 } else {
-                    a[t] = ld_own<LEV>(j0 + t, lq);
-                    b[t] = ld_own<LEV>(c + j0 + t, lq);
+#pragma unroll
+                    for (int t = 0; t < BT; t++) {
+                        a[t] = top_val<false>(j0 + t, tb);
+                        b[t] = top_val<false>(c + j0 + t, tb);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < BT; t++) {
+                    if constexpr (LEV == NLOG) {
+                        a[t] = chs[j0 + t];
+                        b[t] = chs[j0 + t + c];
+                    } else {
+                        a[t] = ld_own<LEV>(j0 + t, lq);
+                        b[t] = ld_own<LEV>(c + j0 + t, lq);
+                    }
                 }
             }
 #pragma unroll
@@ -262,24 +300,48 @@ template <int NLOG, int LMAX, typename T> struct WideDec {
     template <int LEV> __device__ __forceinline__ void step_g()
     {
         constexpr int c = 1 << (LEV - 2);
+        if constexpr (St::RECOMP && LEV == NLOG) {
+            right = true;
+            return;
+        }
+        constexpr bool FROM_TOP = St::RECOMP && LEV == St::TOP;
         constexpr bool MEM = LEV == NLOG || LEV >= 7 || LEV == St::LDS_LEVEL;
         constexpr int BMAX = sizeof(T) == 4 ? 16 : 8;
         constexpr int BT = MEM ? (c < BMAX ? c : BMAX) : (c < 4 ? c : 4);
         const int lq = opaque(lane);
         const int srcP = (int)own_get<LEV - 1>(oP) * 2 + h;
-        const int srcL = opaque((LEV == NLOG) ? 0 : (int)own_get<(LEV == NLOG ? 1 : LEV)>(oL) * 2 + h);
+        const int srcL = opaque((LEV == NLOG || FROM_TOP) ? 0 : (int)own_get<(LEV == NLOG ? 1 : LEV)>(oL) * 2 + h);
         const Bits bits = fetch_bits<c>(srcP);
+        Bits tb{{0, 0, 0, 0}};
+        if constexpr (FROM_TOP)
+            if (right) tb = fetch_bits<(1 << (NLOG - 2))>((int)own_get<St::TOP>(oP) * 2 + h);
 #pragma unroll
         for (int j0 = 0; j0 < c; j0 += BT) {
             T a[BT], b[BT];
+            if constexpr (FROM_TOP) {
+                if (right) {
 #pragma unroll
-            for (int t = 0; t < BT; t++) {
-                if constexpr (LEV == NLOG) {
-                    a[t] = chs[j0 + t];
-                    b[t] = chs[j0 + t + c];
+                    for (int t = 0; t < BT; t++) {
+                        a[t] = top_val<true>(j0 + t, tb);
+                        b[t] = top_val<true>(c + j0 + t, tb);
+                    }
                 } else {
-                    a[t] = ld_from<LEV>(j0 + t, srcL);
-                    b[t] = ld_from<LEV>(c + j0 + t, srcL);
+#pragma unroll
+                    for (int t = 0; t < BT; t++) {
+                        a[t] = top_val<false>(j0 + t, tb);
+                        b[t] = top_val<false>(c + j0 + t, tb);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < BT; t++) {
+                    if constexpr (LEV == NLOG) {
+                        a[t] = chs[j0 + t];
+                        b[t] = chs[j0 + t + c];
+                    } else {
+                        a[t] = ld_from<LEV>(j0 + t, srcL);
+                        b[t] = ld_from<LEV>(c + j0 + t, srcL);
+                    }
                 }
             }
 #pragma unroll
@@ -512,6 +574,7 @@ scl_wide_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, c
         d.oL[0] = d.oL[1] = d.oP[0] = d.oP[1] = 0u;
         d.x = (T)0;
         d.Lcur = 1;
+        d.right = false;
         wave_sync();
         wide_node<NLOG, NLOG, LMAX, T>(d, maskv, 0u, 0, keys, inv);
 
