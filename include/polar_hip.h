@@ -205,6 +205,10 @@ int polar_pbf_decode_packed(polar_code *code, const void *llr, int dtype, int ma
  * file-scope device array of 4 MiB + 256 B that each GPU the library runs on holds until the process ends.
  * Limits: B <= 2^20 frames per call (more is rejected with POLAR_EINVAL), N <= 1024; polar_code_set_crc and (for
  * max_level >= 1) polar_code_set_reliability must have been called: they build every table the search needs.
+ * With max_level = 2 the search runs with one wavefront per failed frame and LDS-staged SC passes (the search in pieces that
+ * polar_pbf_decode_packed uses needs a workspace the array has no room for): same results, several times slower.
+ * The context's timing bracket (polar_ctx_enable_timing) synchronises after each launch, which capture forbids: with it on
+ * the call is refused (POLAR_EINVAL).
  * All calls on one GPU share that array: calls that overlap on one GPU (two streams, two contexts) race. */
 int polar_pbf_decode_noalloc(polar_code *code, const void *llr, int dtype, int max_level, uint32_t *info_hat, int32_t *runs,
                              uint8_t *crc_ok, int32_t *last_seq, int64_t B);

@@ -585,15 +585,23 @@ static int build_big_tables(polar_code *c)
         }
     BigDeviceTables *t = new BigDeviceTables;
     t->KwPad = KwPad;
-    if (hipMalloc((void **)&t->sub, sub.size() * sizeof(NodeClasses)) != hipSuccess || hipMalloc((void **)&t->up, 12 * sizeof(uint64_t)) != hipSuccess ||
-        hipMalloc((void **)&t->gather, gather.size() * 4) != hipSuccess) {
-        polar_set_error("out of device memory for the long-code SC tables");
+    c->big_tables = t;  // from here on sc_big_release gives back whatever exists, also on the error paths below
+    hipError_t e = hipMalloc((void **)&t->sub, sub.size() * sizeof(NodeClasses));
+    if (e == hipSuccess) e = hipMalloc((void **)&t->up, 12 * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&t->gather, gather.size() * 4);
+    if (e != hipSuccess) {
+        polar_set_error("out of device memory for the long-code SC tables: %s", hipGetErrorString(e));
+        sc_big_release(c);
         return POLAR_ENOMEM;
     }
-    HIP_TRY(hipMemcpy(t->sub, sub.data(), sub.size() * sizeof(NodeClasses), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(t->up, up.data(), 12 * sizeof(uint64_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(t->gather, gather.data(), gather.size() * 4, hipMemcpyHostToDevice));
-    c->big_tables = t;
+    e = hipMemcpy(t->sub, sub.data(), sub.size() * sizeof(NodeClasses), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(t->up, up.data(), 12 * sizeof(uint64_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(t->gather, gather.data(), gather.size() * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        polar_set_error("long-code SC tables: %s", hipGetErrorString(e));
+        sc_big_release(c);
+        return POLAR_EHIP;
+    }
     return POLAR_OK;
 }
 

@@ -893,6 +893,8 @@ extern "C" int polar_pbf_decode_noalloc(polar_code *c, const void *llr, int dtyp
     ARG_TRY(max_level >= 0 && max_level <= 3, "max_level must be in [0, 3]");
     ARG_TRY(c->crc_w > 0, "bit flipping needs polar_code_set_crc first");
     ARG_TRY(max_level == 0 || c->have_mu, "bit flipping needs polar_code_set_reliability first");
+    // the timing bracket waits on an event after the launch, which a caller under graph capture must not do
+    ARG_TRY(!c->ctx->timing, "polar_pbf_decode_noalloc: switch polar_ctx_enable_timing off (it synchronises after every launch)");
     if (B > PBF_NOALLOC_MAX_FRAMES) {
         polar_set_error("polar_pbf_decode_noalloc: %lld frames exceed the scratch array's capacity of %lld frames per call",
                         (long long)B, (long long)PBF_NOALLOC_MAX_FRAMES);

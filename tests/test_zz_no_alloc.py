@@ -62,3 +62,11 @@ def test_noalloc_entry_point_rejects_what_it_cannot_hold():
     with pytest.raises(_native.PolarError, match="longer than 1024"):
         code_ptr = torch.zeros(8, dtype=torch.int32, device="cuda")
         big.pbf_decode_noalloc_dev(code_ptr.data_ptr(), np.float32, 1, code_ptr.data_ptr(), 1)
+    # the timing bracket synchronises after every launch, which a caller under graph capture must not do
+    ctx.enable_timing(True)
+    try:
+        with pytest.raises(_native.PolarError, match="enable_timing"):
+            buf = torch.zeros(1024, dtype=torch.int32, device="cuda")
+            code.pbf_decode_noalloc_dev(buf.data_ptr(), np.float32, 1, buf.data_ptr(), 1)
+    finally:
+        ctx.enable_timing(False)
