@@ -124,6 +124,10 @@ std::vector<uint32_t> build_compress_tables(const uint8_t *mask, int N)
             for (int i = 0; i < 4; i++) per_lane[5 * w + 1 + i] |= mv[i] << sh;
             const int off = p0 < N ? rank[p0] : 0;
             per_lane[10 + q] = (uint32_t)(4 * (off >> 5)) | ((uint32_t)(off & 31) << 16);
+            // the compressed piece: as many low bits as the halfword has information positions (the encoder side of the
+            // Monte-Carlo kernel cuts a piece out of the information words with it before expanding)
+            const int cnt = __builtin_popcount(m);
+            per_lane[14 + w] |= (cnt >= 16 ? 0xFFFFu : ((1u << cnt) - 1u)) << sh;
         }
         for (int j = 0; j < 16; j++) tab[(size_t)(16 * (j >> 2) + l) * 4 + (j & 3)] = per_lane[j];
     }

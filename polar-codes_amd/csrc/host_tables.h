@@ -45,7 +45,8 @@ void build_crc_tables(uint64_t crc_poly, int w, int K, std::vector<uint32_t> &E,
 // the four move masks that compress each halfword's information bits towards its bit 0 (parallel suffix method, 16-bit
 // halves handled independently); per lane and halfword: where the compressed piece goes in the frame's information
 // words, as (byte offset of the word) | (bit offset << 16).  Layout: word (4 g + i) of lane l at [(16 g + l) * 4 + i];
-// per lane words 0 .. 4 = mask, moves of slice word 0, 5 .. 9 = of slice word 1, 10 .. 13 = the four places.
+// per lane words 0 .. 4 = mask, moves of slice word 0, 5 .. 9 = of slice word 1, 10 .. 13 = the four places, 14 .. 15 = per
+// slice word the low-bit masks of its two compressed pieces (as many ones as the halfword has information positions).
 std::vector<uint32_t> build_compress_tables(const uint8_t *mask, int N);
 
 

@@ -159,6 +159,7 @@ struct ChannelGen {
     uint32_t xlo, xhi;
     float sigma, gain;
     int sub;
+    float *xq;  // 4 floats of LDS per lane, the lane's own at xq[0..3], its quad's first lane's at xq[-4 (sub & 3)]: the 4 x 4 exchange
 };
 template <int NLOG_, int KEEP = 0, int KL = 0, bool GEN = false> struct StaticDec {
     static constexpr int NLOG = NLOG_;
@@ -181,6 +182,7 @@ template <int NLOG_, int KEEP = 0, int KL = 0, bool GEN = false> struct StaticDe
         float z[4];
         box_muller<float>(r[0], r[1], z[0], z[1]);
         box_muller<float>(r[2], r[3], z[2], z[3]);
+#ifdef POLAR_MC_QUAD_DPP
         const bool b0 = (b & 1) != 0, b1 = (b & 2) != 0;
         {
             const float r01 = dpp_mov<0xB1>(b0 ? z[0] : z[1]), r23 = dpp_mov<0xB1>(b0 ? z[2] : z[3]);  // partner b ^ 1
@@ -202,10 +204,27 @@ template <int NLOG_, int KEEP = 0, int KL = 0, bool GEN = false> struct StaticDe
                 z[3] = r13;
             }
         }
+#else
+        // the transpose through LDS: one 16-byte write and two paired reads per lane instead of two exchange steps of
+        // selects and DPP moves (16 vector instructions per group; the vector ALU is what this kernel is short of)
+        {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            wave_sync();  // the previous group's reads are done
+            *reinterpret_cast<f4 *>(cg.xq) = f4{z[0], z[1], z[2], z[3]};
+            wave_sync();
+            const float *col = cg.xq - 4 * b + b;  // element b of the quad's lane 0; lane i's is 4 floats further
+            z[0] = col[0];
+            z[1] = col[4];
+            z[2] = col[8];
+            z[3] = col[12];
+        }
+#endif
         const uint32_t xw = (4 * G < 32) ? cg.xlo : cg.xhi;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const float s = ((xw >> ((4 * G + i) & 31)) & 1u) ? -1.0f : 1.0f;
+            // BPSK: +1 for a zero, -1 for a one -- the code bit moved to the sign position of the constant 1.0 (two instructions;
+            // as a comparison and a select it was three)
+            const float s = __uint_as_float(((xw << (31 - ((4 * G + i) & 31))) & 0x80000000u) | 0x3F800000u);
             out[i] = cg.gain * (s + cg.sigma * z[i]);
         }
     }
@@ -587,6 +606,46 @@ __device__ __forceinline__ uint32_t compress_halves(uint32_t x, uint32_t m, uint
     x = (x ^ t) | (t >> 8);
     return x;
 }
+// the inverse: the low bits of both halfwords of x (already cut to as many bits as the halfword has information
+// positions) moved up to those positions; the moves of compress_halves undone in reverse order
+__device__ __forceinline__ uint32_t expand_halves(uint32_t x, uint32_t m, uint32_t mv0, uint32_t mv1, uint32_t mv2, uint32_t mv3)
+{
+    uint32_t t;
+    t = x & (mv3 >> 8);
+    x = (x ^ t) | (t << 8);
+    t = x & (mv2 >> 4);
+    x = (x ^ t) | (t << 4);
+    t = x & (mv1 >> 2);
+    x = (x ^ t) | (t << 2);
+    t = x & (mv0 >> 1);
+    x = (x ^ t) | (t << 1);
+    return x & m;
+}
+// The rate profile u[polarMask == 1] = info (cn/polarCode.py:225-230) on the sliced layout, as the inverse of the output
+// stage below: the frame's information words lie in row[0 .. Kw) (LDS, 64 words per row, the rest zero or anything);
+// every lane cuts the pieces of its (at most four) 16-position halfwords out of them at the bit offsets of the table,
+// expands them to the information positions and the 16 x 16 transpose across the row puts them on the sliced layout.
+// Returns the lane's two slice words of u (zero at frozen positions).
+template <int NLOG>
+__device__ __forceinline__ void sc_reg_profile_c(const uint32_t *row, const uint32_t *ctab, int sub, const RowConst &rc, uint32_t &u_lo, uint32_t &u_hi)
+{
+    const uint4 c0 = *reinterpret_cast<const uint4 *>(ctab + 4 * sub);          // mask and moves 0 .. 2 of slice word 0
+    const uint4 c1 = *reinterpret_cast<const uint4 *>(ctab + 64 + 4 * sub);     // move 3 of word 0; mask, moves 0, 1 of word 1
+    const uint4 c2 = *reinterpret_cast<const uint4 *>(ctab + 128 + 4 * sub);    // moves 2, 3 of word 1; places of halfwords 0, 1
+    const uint4 c3 = *reinterpret_cast<const uint4 *>(ctab + 192 + 4 * sub);    // places of halfwords 2, 3; low masks of words 0, 1
+    auto piece = [&](uint32_t e) {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(row) + (e & 0xFFFFu));
+        return __builtin_amdgcn_alignbit(src[1], src[0], e >> 16);  // 32 bits of the stream from the piece's first bit on
+    };
+    uint32_t lo = piece(c2.z) & 0xFFFFu;
+    if constexpr (NLOG > 8) lo |= piece(c2.w) << 16;
+    u_lo = row_transpose16(expand_halves(lo & c3.z, c0.x, c0.y, c0.z, c0.w, c1.x), rc);
+    u_hi = 0u;
+    if constexpr (NLOG > 9) {
+        const uint32_t hi = (piece(c3.x) & 0xFFFFu) | (piece(c3.y) << 16);
+        u_hi = row_transpose16(expand_halves(hi & c3.w, c1.y, c1.z, c1.w, c2.x, c2.y), rc);
+    }
+}
 // Information words sub and sub + 16 of the lane's frame from the root partial sums, without touching one bit at a time:
 // u_hat on the sliced layout, a 16 x 16 bit transpose across the row (lane l then holds code positions 16 (l + 16 q) ..
 // + 15 in halfword q of its slice), the information bits of every halfword compressed to its low end, and the (at most
@@ -714,7 +773,7 @@ extern "C" __global__ void __launch_bounds__(64 * SC_STATIC_WAVES, POLAR_STATIC_
 // the four frames.  Counters and every intermediate value are those of gen_frames_kernel followed by
 // sc_static_kernel: same Philox blocks, same arithmetic.  counters: frames, frame errors, bit errors.
 extern "C" __global__ void __launch_bounds__(64 * SC_STATIC_WAVES, POLAR_STATIC_WAVES) sc_static_mc_kernel(
-    const uint16_t *__restrict__ Asl, long long B, int K, int Kw, float sigma, float gain, unsigned long long seed,
+    const uint32_t *__restrict__ ctab, long long B, int K, int Kw, float sigma, float gain, unsigned long long seed,
     unsigned long long frame0, unsigned long long *__restrict__ counters)
 {
     constexpr int NLOG = POLAR_STATIC_NLOG;
@@ -723,12 +782,11 @@ extern "C" __global__ void __launch_bounds__(64 * SC_STATIC_WAVES, POLAR_STATIC_
     constexpr int KL = PAIRS > 16 ? 16 : 0;  // this kernel has the generator's registers to feed as well: 16 pairs in registers
     constexpr int KEEP = PAIRS - KL;
     constexpr int KEPT = 2 * KL * 64;
-    constexpr int TW = GatherShape<NLOG>::TW;
     __shared__ __attribute__((aligned(32))) uint32_t stage_s[SC_STATIC_WAVES * SC_STAGE_WORDS];
-    __shared__ uint16_t asl_s[GatherShape<NLOG>::WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t ctab_s[256];
     __shared__ float kept_s[SC_STATIC_WAVES * (KEPT > 0 ? KEPT : 1)];
     __shared__ uint32_t count_s[3];
-    for (int k = threadIdx.x; k < GatherShape<NLOG>::WORDS; k += 64 * SC_STATIC_WAVES) asl_s[k] = Asl[k];
+    for (int k = threadIdx.x; k < 256; k += 64 * SC_STATIC_WAVES) ctab_s[k] = ctab[k];
     if (threadIdx.x < 3) count_s[threadIdx.x] = 0u;
     __syncthreads();
     const int wave = threadIdx.x >> 6;
@@ -750,6 +808,7 @@ extern "C" __global__ void __launch_bounds__(64 * SC_STATIC_WAVES, POLAR_STATIC_
     d.cg.sigma = sigma;
     d.cg.gain = gain;
     d.cg.sub = sub;
+    d.cg.xq = reinterpret_cast<float *>(stage) + 4 * lane;  // the staging words are idle while the channel is made
     const long long stride = (long long)gridDim.x * (4 * SC_STATIC_WAVES);
     for (long long f0 = ((long long)blockIdx.x * SC_STATIC_WAVES + wave) * 4; f0 < B; f0 += stride) {
         const long long f = f0 + grp;
@@ -770,29 +829,22 @@ extern "C" __global__ void __launch_bounds__(64 * SC_STATIC_WAVES, POLAR_STATIC_
                 iw[s] = v;
             }
         }
-        // rate profile: information bit 32 w + i goes where the output stage would fetch it from
-#pragma unroll
-        for (int i = 0; i < SC_STAGE_WORDS / 64; i++) stage[lane + 64 * i] = 0u;
+        // rate profile: the information words go to the frame's row of the staging area and every lane takes the bits of
+        // its own code positions out of them (the output stage run backwards; no bit is moved on its own)
+        uint32_t *row = stage + 64 * grp;
+        wave_sync();  // the last frame's exchanges through these words are done
+        row[sub] = iw[0];
+        row[sub + 16] = iw[1];
+        row[sub + 32] = 0u;
         wave_sync();
+        uint32_t xlo, xhi;
         {
-            unsigned char *base = reinterpret_cast<unsigned char *>(stage);
-            const uint32_t goff = (uint32_t)grp << 2;
-#pragma unroll
-            for (int s = 0; s < 2; s++) {
-                // only lanes that drew a word take part: an LDS atomic costs by the lanes it serves, and short codes have
-                // few information words per frame
-                if ((s == 0 || (TW > 16 && Kw > 16)) && sub + 16 * s < Kw) {
-                    const uint16_t *t = asl_s + sub + 16 * s;
-#pragma unroll
-                    for (int i = 0; i < 32; i++) {
-                        const uint32_t e = t[i * TW];  // unused entries meet zero bits only
-                        atomicOr(reinterpret_cast<uint32_t *>(base + ((e & ~31u) | goff)), ((iw[s] >> i) & 1u) << (e & 31u));
-                    }
-                }
-            }
+            // the table words are the same for every frame of the lane: read through an index the compiler cannot see through,
+            // or it keeps all sixteen in registers across the decoder (22 spill slots)
+            int sq = sub;
+            asm volatile("" : "+v"(sq));
+            sc_reg_profile_c<NLOG>(row, ctab_s, sq, rc, xlo, xhi);
         }
-        wave_sync();
-        uint32_t xlo = stage[16 * sub + grp], xhi = (NLOG > 9) ? stage[16 * sub + 8 + grp] : 0u;
         wave_sync();
         const uint32_t ulo = xlo, uhi = xhi;   // the transmitted u, sliced: zero at frozen positions
         slice_transform<NLOG>(xlo, xhi, sub);  // u -> x

@@ -90,18 +90,20 @@ __device__ __forceinline__ uint64_t bperm_key(uint64_t k, int byte_addr)
     return ((uint64_t)hi << 32) | lo;
 }
 
-// a real number in the word-major exchange records of the pruning step (word w of a record at rec[64 * w])
-__device__ __forceinline__ void rec_put(uint32_t *rec, int &w, float v) { rec[64 * w++] = __float_as_uint(v); }
+// a real number in the word-major exchange records of the pruning step (word w of a record at rec[RS * w]); a word row holds
+// the records of the eight list positions and one more that takes the writes of the candidates that do not survive
+constexpr int RS = 72;
+__device__ __forceinline__ void rec_put(uint32_t *rec, int &w, float v) { rec[RS * w++] = __float_as_uint(v); }
 __device__ __forceinline__ void rec_put(uint32_t *rec, int &w, double v)
 {
-    rec[64 * w++] = (uint32_t)__double2loint(v);
-    rec[64 * w++] = (uint32_t)__double2hiint(v);
+    rec[RS * w++] = (uint32_t)__double2loint(v);
+    rec[RS * w++] = (uint32_t)__double2hiint(v);
 }
-__device__ __forceinline__ void rec_get(const uint32_t *rec, int &w, float &v) { v = __uint_as_float(rec[64 * w++]); }
+__device__ __forceinline__ void rec_get(const uint32_t *rec, int &w, float &v) { v = __uint_as_float(rec[RS * w++]); }
 __device__ __forceinline__ void rec_get(const uint32_t *rec, int &w, double &v)
 {
-    const uint32_t lo = rec[64 * w++];
-    const uint32_t hi = rec[64 * w++];
+    const uint32_t lo = rec[RS * w++];
+    const uint32_t hi = rec[RS * w++];
     v = __hiloint2double((int)hi, (int)lo);
 }
 
@@ -552,10 +554,12 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
         const T mt[2] = {cpm, cpm_o};
 #pragma unroll
         for (int u = 0; u < 2; u++) {  // my own candidate, then my path's other one
-            if (rk[u] < Lmax) {
-                uint32_t *rec = xch + rk[u] * 8 + lc.q;
+            {
+                // candidates that do not survive write as well, into the spare record: cheaper than a branch on the lane's rank
+                const int slot = rk[u] < Lmax ? rk[u] : 8;
+                uint32_t *rec = xch + slot * 8 + lc.q;
                 rec[0] = st.ownL;
-                rec[64] = ((uint32_t)a0 & ~1u) | (bme ^ (uint32_t)u);  // bit 0 of a0 belongs to no level; u = 0: my own candidate
+                rec[RS] = ((uint32_t)a0 & ~1u) | (bme ^ (uint32_t)u);  // bit 0 of a0 belongs to no level; u = 0: my own candidate
                 int w = 2;
                 rec_put(rec, w, mt[u]);
 #pragma unroll
@@ -570,7 +574,7 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
         wave_sync();
         const uint32_t *mine = xch + lc.lane;
         st.ownL = mine[0];
-        const uint32_t op = mine[64];
+        const uint32_t op = mine[RS];
         {
             int w = 2;
             rec_get(mine, w, st.pm);
@@ -888,7 +892,7 @@ scl_reg_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, co
     // survivor table of the general leaf, and the whole area as the staging buffer of the output stage (8 paths x 8 lanes x
     // 128-bit slice of u_hat)
     constexpr int XW = 2 + (EAGER_L_TOP >= 4 ? 6 : 4) * (int)(sizeof(T) / 4);
-    __shared__ uint32_t xchg[64 * XW];
+    __shared__ uint32_t xchg[RS * XW];
     uint32_t *const surv = xchg;
     uint32_t *const stage = xchg;
     uint32_t *const passw = xchg + 320;  // bitmap of the list entries that pass the CRC / equal the transmitted word
@@ -1167,7 +1171,7 @@ static int launch_scl_reg_t(polar_code *c, const void *llr, uint32_t *info_hat, 
     if (sizeof(T) == 4) snprintf(c->last.kernel, sizeof(c->last.kernel), "scl_reg_kernel<%d>/L%d", NLOG, LMAX);
     else snprintf(c->last.kernel, sizeof(c->last.kernel), "scl_reg_kernel<%d,double>/L%d", NLOG, LMAX);
     c->last.lanes_per_frame = 64;
-    c->last.lds_bytes_per_block = 64 * 4 * (2 + (EAGER_L_TOP >= 4 ? 6 : 4) * (int)(sizeof(T) / 4)) + (NLOG < 10 ? 2 * c->N : 2) + (int)sizeof(T) * St::LDS_VALUES;
+    c->last.lds_bytes_per_block = RS * 4 * (2 + (EAGER_L_TOP >= 4 ? 6 : 4) * (int)(sizeof(T) / 4)) + (NLOG < 10 ? 2 * c->N : 2) + (int)sizeof(T) * St::LDS_VALUES;
     c->last.block_threads = 64;
     c->last.grid_blocks = (int)grid;
     c->last.last_ms = ms;

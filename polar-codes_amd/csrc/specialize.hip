@@ -157,7 +157,7 @@ int launch_sc_static_mc(polar_code *c, int64_t B, double N0, uint64_t seed, uint
     const int64_t per_block = 4 * WAVES;
     const int64_t need = (B + per_block - 1) / per_block;
     const int64_t grid = std::min<int64_t>(need, (int64_t)ctx->num_cus * occ * 32);
-    const void *a_asl = c->d_Asl;
+    const void *a_asl = c->d_ctab;  // the output stage's table, read backwards by the encoder side
     long long a_B = (long long)B;
     int a_K = c->K, a_Kw = c->Kw;
     float a_sigma = (float)sqrt(N0 / 2.0), a_gain = (float)(4.0 / N0);  // as launch_gen_frames passes them

@@ -93,6 +93,64 @@ def test_output_stage_tables_and_method(N, K, cons):
         assert not out[Kw:].any()
 
 
+def expand_halves(x, m, mv):
+    for i in (3, 2, 1, 0):
+        t = x & (mv[i] >> np.uint64(1 << i))
+        x = (x ^ t) | (t << np.uint64(1 << i))
+    return x & m
+
+
+@pytest.mark.parametrize("N,K,cons", [(128, 64, "dega"), (256, 200, "dega"), (512, 256, "rmpolar"), (1024, 512, "dega"), (1024, 1000, "dega"),
+                                        (1024, 40, "dega"), (512, 300, "random"), (1024, 777, "random")])
+def test_rate_profile_as_the_output_stage_run_backwards(N, K, cons):
+    """The encoder side of the one-kernel Monte-Carlo loop: u[polarMask == 1] = info (cn/polarCode.py:225-230) on the sliced
+    layout, made from the information words by cutting every lane's pieces out at the table's bit offsets, masking them to
+    the halfword's number of information positions (table entries 14, 15), undoing the compress moves in reverse order
+    and transposing -- restated in numpy on the library's tables and compared with the scatter done bit by bit."""
+    rs = np.random.RandomState(N * 3 + K)
+    if cons == "random":
+        mask = np.zeros(N, dtype=np.uint8)
+        mask[rs.choice(N, K, replace=False)] = 1
+    else:
+        mask = (pcf.degaBuild(N, K, 2.0) if cons == "dega" else pcf.rmPolarBuild(N, K, 2.0)).astype(np.uint8)
+    tab = _native.output_tables(mask).astype(np.uint64)
+    per_lane = np.zeros((16, 16), dtype=np.uint64)
+    for j in range(16):
+        for l in range(16):
+            per_lane[l, j] = tab[(16 * (j >> 2) + l) * 4 + (j & 3)]
+    low = lane_constants()
+    for trial in range(12):
+        info = rs.randint(0, 2, K)
+        if trial == 0:
+            info[:] = 1
+        row = np.zeros(64, dtype=np.uint64)
+        for k, bit in enumerate(info):
+            row[k >> 5] |= np.uint64(int(bit) << (k & 31))
+        row[(K + 31) // 32:] = rs.randint(0, 1 << 32, 64 - (K + 31) // 32, dtype=np.uint64)  # whatever lies behind the words is cut off
+        row[(K + 31) // 32 - 1] |= np.uint64(((1 << 32) - 1) ^ ((1 << (((K - 1) & 31) + 1)) - 1)) if K & 31 else np.uint64(0)
+        got = np.zeros((2, 16), dtype=np.uint64)
+        for w in range(2 if N > 512 else 1):
+            x = np.zeros(16, dtype=np.uint64)
+            for half in range(2):
+                q = 2 * w + half
+                if 16 * 16 * q >= N:
+                    continue
+                e = per_lane[:, 10 + q]
+                for l in range(16):
+                    at, sh = int(e[l] & np.uint64(0xFFFF)) // 4, int(e[l] >> np.uint64(16))
+                    stream = (int(row[at]) | (int(row[at + 1]) << 32)) >> sh
+                    x[l] |= np.uint64((stream & 0xFFFF) << (16 * half))
+            x = expand_halves(x & per_lane[:, 14 + w], per_lane[:, 5 * w], [per_lane[:, 5 * w + 1 + i] for i in range(4)])
+            got[w] = row_transpose16(x, low)
+        u = np.zeros(N, dtype=np.uint64)
+        u[mask == 1] = info
+        want = np.zeros((2, 16), dtype=np.uint64)
+        for k in range(N):
+            j, s = k >> 4, k & 15
+            want[j >> 5, s] |= u[k] << np.uint64(j & 31)
+        assert np.array_equal(got, want), trial
+
+
 def test_output_tables_argument_errors():
     with pytest.raises(_native.PolarError):
         _native.output_tables(np.ones(2048, dtype=np.uint8))
