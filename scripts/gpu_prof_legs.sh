@@ -21,11 +21,17 @@ for _ in range(2): code.sc_decode_dev(llr.data_ptr(),np.float32,hat.data_ptr(),1
 code,n0,llr,info,hat=frames(pcf.degaBuild(1024,536,2.0),1<<18,Kmsg=512); code.set_crc(0x1800063); code.set_reliability(pcf.GA(1024,536,2.0))
 code.gen_frames_dev(info.data_ptr(),llr.data_ptr(),np.float32,n0,1,0,1<<18,crc=True)
 for _ in range(2): code.pbf_decode_dev(llr.data_ptr(),np.float32,2,hat.data_ptr(),1<<18)
-# the reference's arithmetic (fp64): every-leaf SC with decision LLRs, list decoder with the sorted list's metrics
+# the reference's arithmetic (fp64), the calls bench.py times: every-leaf SC (information bits out, as in the bench leg),
+# list decoder with the sorted list's metrics, the two-lanes-per-path list decoder with L = 32
 code,n0,llr,info,hat=frames(pcf.degaBuild(1024,512,2.0),1<<17,tdt=torch.float64); code.gen_frames_dev(info.data_ptr(),llr.data_ptr(),np.float64,n0,1,0,1<<17)
-dl=torch.empty_like(llr); pm=torch.empty((1<<17,8),dtype=torch.float64,device='cuda')
-for _ in range(2): code.sc_decode_dev(llr.data_ptr(),np.float64,hat.data_ptr(),1<<17,fast=False,dec_llr_ptr=dl.data_ptr())
+pm=torch.empty((1<<17,8),dtype=torch.float64,device='cuda')
+for _ in range(2): code.sc_decode_dev(llr.data_ptr(),np.float64,hat.data_ptr(),1<<17,fast=False)
 for _ in range(2): code.scl_decode_dev(llr.data_ptr(),np.float64,8,hat.data_ptr(),1<<17,pm_ptr=pm.data_ptr())
+code,n0,llr,info,hat=frames(pcf.rmPolarBuild(512,256,2.0),1<<16,tdt=torch.float64); code.gen_frames_dev(info.data_ptr(),llr.data_ptr(),np.float64,n0,1,0,1<<16)
+for _ in range(2): code.scl_decode_dev(llr.data_ptr(),np.float64,32,hat.data_ptr(),1<<16)
+# the one-kernel Monte-Carlo loop of a specialised code
+code=_native.Code(ctx,pcf.degaBuild(1024,512,2.0)); code.specialize()
+for _ in range(2): code.mc_run(_native.DEC_SC,1,np.float32,Channel('BPSK',2.0,'SNRb',0.5).noisePower,2024,0,1<<24)
 ctx.sync()
 PY
 rm -rf $R/gpurun_out/prof_legs; timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_legs -- python3 /tmp/legs.py > $R/gpurun_out/prof_legs.log 2>&1 || { tail -5 $R/gpurun_out/prof_legs.log; exit 1; }
@@ -37,14 +43,16 @@ cp $R/gpurun_out/prof_legs/*/*kernel_stats.csv $R/gpurun_out/legs_kernel_stats.c
 python3 - <<PY
 import csv,glob,collections,json
 legs={'scl_reg_kernel<10, 8, float>':(1<<19,4*1024+64,'(1024,512) L=8'),'scl_reg_kernel<10, 8, double>':(1<<17,8*1024+64,'(1024,512) L=8 fp64, sorted metrics out'),
-      'sc_reg_full_kernel<double, 10>':(1<<17,16*1024+64,'(1024,512) SC fp64, every leaf, decision LLRs out'),'scl_wide_kernel':(1<<17,4*512+32,'rmpolar (512,256) L=32'),'sc_big_kernel':(1<<15,4*16384+1024,'(16384,8192) SC'),
+      'sc_reg_full_kernel<double, 10>':(1<<17,8*1024+64,'(1024,512) SC fp64, every leaf, information bits out (the call bench.py times)'),
+      'scl_wide_kernel<9, 32, float>':(1<<17,4*512+32,'rmpolar (512,256) L=32'),'scl_wide_kernel<9, 32, double>':(1<<16,8*512+32,'rmpolar (512,256) L=32 fp64'),
+      'sc_static_mc_kernel':(1<<24,24.0/(1<<24),'(1024,512) one-kernel Monte-Carlo loop, 2^24 frames'),'sc_big_kernel':(1<<15,4*16384+1024,'(16384,8192) SC'),
       'pbf_reg_kernel<float, 10, 0>':(1<<18,None,'(1024,536) CRC-24 flip search, single flips, 2^18 frames in the batch'),
-      'pbf_reg_kernel<float, 10, 1>':(1<<18,None,'same, pair search'),'sc_static':(0,0,'')}
+      'pbf_reg_kernel<float, 10, 1>':(1<<18,None,'same, pair search')}
 agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sorted(glob.glob('$R/gpurun_out/pmclegs_*/*/*_counter_collection.csv')):
     for r in csv.DictReader(open(d)):
         for name in legs:
-            if name in r['Kernel_Name']: agg[name][r['Counter_Name']].append(float(r['Counter_Value']))
+            if name in r['Kernel_Name'].replace('(anonymous namespace)::',''): agg[name][r['Counter_Name']].append(float(r['Counter_Value']))
 out={}
 with open('$R/gpurun_out/legs_sq_counters.txt','w') as f:
     f.write('scripts/gpu_prof_legs.sh: counters per launch (average over launches) and per frame of the batch\\n')
@@ -56,7 +64,7 @@ with open('$R/gpurun_out/legs_sq_counters.txt','w') as f:
         for k in sorted(m): f.write('  %-22s %.4g  per_frame=%.1f\\n'%(k,m[k],m[k]/nb))
         if 'FETCH_SIZE' in m and 'WRITE_SIZE' in m:
             per=(2*m['FETCH_SIZE']+m['WRITE_SIZE'])*1024/nb   # gfx950 tallies 128-byte read requests at 64 bytes
-            f.write('  HBM bytes per frame    %.0f%s\\n'%(per,' = %.2f x algorithmic %d'%(per/alg,alg) if alg else ''))
+            f.write('  HBM bytes per frame    %.0f%s\\n'%(per,' = %.2f x algorithmic %.0f'%(per/alg,alg) if alg else ''))
             out[name]={'what':what,'bytes_per_frame':per,'algorithmic_bytes_per_frame':alg,'FETCH_SIZE_KiB':m['FETCH_SIZE'],'WRITE_SIZE_KiB':m['WRITE_SIZE'],'frames_per_launch':nb}
 json.dump(out,open('$R/gpurun_out/traffic_legs.json','w'),indent=1)
 print(open('$R/gpurun_out/legs_sq_counters.txt').read())
