@@ -481,6 +481,20 @@ def main():
                                                "kernel": li["kernel"], "kernel_ms": li["last_ms"], "frames": nb,
                                                "roofline": leg_roofline(li["kernel"], li["last_ms"], nb, N, K, paths=8, hbm_bytes_per_frame=8 * N + K / 8)}
             del l64, h64, pm64
+            # the rate-profiled (512,256) code with L = 32 in fp64, sorted metrics as an output: two lanes per path
+            nb = 1 << 16
+            c512d = _native.Code(ctx, pcf.rmPolarBuild(512, 256, 2.0))
+            l512d = torch.empty((nb, 512), dtype=torch.float64, device=dev)
+            c512d.gen_frames_dev(None, l512d.data_ptr(), np.float64, ch.noisePower, seed, 0, nb)
+            h512d = torch.empty((nb, c512d.Kw), dtype=torch.int32, device=dev)
+            pm512d = torch.empty((nb, 32), dtype=torch.float64, device=dev)
+            for _ in range(2):
+                c512d.scl_decode_dev(l512d.data_ptr(), np.float64, 32, h512d.data_ptr(), nb, pm_ptr=pm512d.data_ptr())
+            li = c512d.last_launch()
+            extras["scl32_fp64_parity_mode_rmpolar_512_256"] = {
+                "frames_per_s": nb / (li["last_ms"] * 1e-3), "kernel": li["kernel"], "kernel_ms": li["last_ms"], "frames": nb,
+                "roofline": leg_roofline(li["kernel"], li["last_ms"], nb, 512, 256, paths=32, hbm_bytes_per_frame=8 * 512 + 256 / 8)}
+            del l512d, h512d, pm512d
         except _native.PolarError as e:
             extras["fp64_error"] = str(e)
         ctx.enable_timing(False)

@@ -45,7 +45,7 @@ import csv,glob,collections,json
 legs={'scl_reg_kernel<10, 8, float>':(1<<19,4*1024+64,'(1024,512) L=8'),'scl_reg_kernel<10, 8, double>':(1<<17,8*1024+64,'(1024,512) L=8 fp64, sorted metrics out'),
       'sc_reg_full_kernel<double, 10>':(1<<17,8*1024+64,'(1024,512) SC fp64, every leaf, information bits out (the call bench.py times)'),
       'scl_wide_kernel<9, 32, float>':(1<<17,4*512+32,'rmpolar (512,256) L=32'),'scl_wide_kernel<9, 32, double>':(1<<16,8*512+32,'rmpolar (512,256) L=32 fp64'),
-      'sc_static_mc_kernel':(1<<24,24.0/(1<<24),'(1024,512) one-kernel Monte-Carlo loop, 2^24 frames'),'sc_big_kernel':(1<<15,4*16384+1024,'(16384,8192) SC'),
+      'sc_static_mc_kernel':(1<<24,None,'(1024,512) one-kernel Monte-Carlo loop, 2^24 frames'),'sc_big_kernel':(1<<15,4*16384+1024,'(16384,8192) SC'),
       'pbf_reg_kernel<float, 10, 0>':(1<<18,None,'(1024,536) CRC-24 flip search, single flips, 2^18 frames in the batch'),
       'pbf_reg_kernel<float, 10, 1>':(1<<18,None,'same, pair search')}
 agg=collections.defaultdict(lambda: collections.defaultdict(list))
