@@ -107,6 +107,20 @@ __device__ __forceinline__ void rec_get(const uint32_t *rec, int &w, double &v)
     v = __hiloint2double((int)hi, (int)lo);
 }
 
+// Word w of the record at LDS byte address `addr`, read INTO the register that holds the old value of the same quantity:
+// the three exits of a leaf (sure, ranked without a move, moved) then leave every piece of path state in one register and
+// meet without copies (as plain loads the new values get registers of their own -- pairs, when two reads are merged -- and
+// the other two exits copy theirs over: five moves per leaf).  The caller waits with rec_wait() before using the values.
+template <int W> __device__ __forceinline__ void rec_get_into(uint32_t &dst, uint32_t addr)
+{
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "+v"(dst) : "v"(addr), "n"(4 * RS * W) : "memory");
+}
+template <int W> __device__ __forceinline__ void rec_get_into(float &dst, uint32_t addr)
+{
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "+v"(dst) : "v"(addr), "n"(4 * RS * W) : "memory");
+}
+__device__ __forceinline__ void rec_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // fp64 branch metric: the reference's expression, operation by operation (cn/polarCode.py:982-988 and :2066-2067, as
 // scl_decode_kernel<double, L> evaluates it)
 __device__ __forceinline__ double branch_metric_fast(double v, uint32_t u)
@@ -285,25 +299,33 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
             wave_sync();
         }
     }
-    uint64_t a0, a1;      // plane 0 partial sums: levels with <= 32 bits per lane in a0 (offset = bit count), 64-bit level in a1
-    uint64_t b0, b1;      // plane 1
+    // plane 0 partial sums: levels with <= 16 bits per lane in a0 (a level of C bits at bit offset C), the 32-bit level in
+    // a0h, the 64-bit level in a1; 32-bit words where the levels allow it: a word of its own moves with a path at a prune,
+    // and 64-bit shifts cost several instructions
+    uint32_t a0, a0h;
+    uint64_t a1;
+    uint32_t b0, b0h;     // plane 1
+    uint64_t b1;
     uint64_t r0, r1;      // root (S bits)
     PathState<T> st;
     int Lcur;
     static constexpr int Lmax = LMAX;   // list size 2, 4 or 8: positions >= Lmax stay empty
 
-    template <int C> static __device__ __forceinline__ uint64_t get_bits(uint64_t w0, uint64_t w1)
+    template <int C> static __device__ __forceinline__ uint64_t get_bits(uint32_t w0, uint32_t w0h, uint64_t w1)
     {
         if constexpr (C == 64) return w1;
-        else return (w0 >> C) & (((uint64_t)1 << C) - 1);
+        else if constexpr (C == 32) return (uint64_t)w0h;
+        else return (uint64_t)((w0 >> C) & ((1u << C) - 1u));
     }
-    template <int C> static __device__ __forceinline__ void set_bits(uint64_t &w0, uint64_t &w1, uint64_t x)
+    template <int C> static __device__ __forceinline__ void set_bits(uint32_t &w0, uint32_t &w0h, uint64_t &w1, uint64_t x)
     {
         if constexpr (C == 64) {
             w1 = x;
+        } else if constexpr (C == 32) {
+            w0h = (uint32_t)x;
         } else {
-            const uint64_t m = (((uint64_t)1 << C) - 1) << C;
-            w0 = (w0 & ~m) | (x << C);
+            const uint32_t m = ((1u << C) - 1u) << C;
+            w0 = (w0 & ~m) | ((uint32_t)x << C);
         }
     }
     static __device__ __forceinline__ uint32_t own_get(uint32_t row, int lev) { return (row >> (3 * (lev - 3))) & 7u; }
@@ -363,11 +385,11 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
         if constexpr (LEV == NLOG) chan_lane = opaque(chan_lane);
         uint64_t bits;
         if constexpr (LEV - 1 <= EAGER_P_TOP) {
-            bits = (uint64_t)(((uint32_t)a0 >> c) & ((1u << c) - 1u));
+            bits = (uint64_t)((a0 >> c) & ((1u << c) - 1u));
         } else {
             const int srcP = (int)ownp_get(st.ownL, LEV - 1) * 8 + lc.q;
             if constexpr (c == 64) bits = bperm_u64(a1, srcP);
-            else bits = (uint64_t)bperm_u((uint32_t)(a0 >> 32), srcP);
+            else bits = (uint64_t)bperm_u(a0h, srcP);
         }
         // operands are level LEV, results level LEV-1: no lane overwrites what another still reads
 #pragma unroll
@@ -398,13 +420,13 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
         constexpr int c = 1 << (LEV - 4);  // bits per lane of each child
         uint64_t xl;
         if constexpr (LEV - 1 <= EAGER_P_TOP) {
-            xl = (uint64_t)(((uint32_t)a0 >> c) & ((1u << c) - 1u));
+            xl = (uint64_t)((a0 >> c) & ((1u << c) - 1u));
         } else {
             const int srcP = (int)ownp_get(st.ownL, LEV - 1) * 8 + lc.q;
             if constexpr (c == 64) xl = bperm_u64(a1, srcP);
-            else xl = (uint64_t)bperm_u((uint32_t)(a0 >> 32), srcP);
+            else xl = (uint64_t)bperm_u(a0h, srcP);
         }
-        const uint64_t xr = get_bits<c>(b0, b1);
+        const uint64_t xr = get_bits<c>(b0, b0h, b1);
         if constexpr (LEV == NLOG) {
             if constexpr (c == 64) {
                 r0 = xl ^ xr;
@@ -416,9 +438,9 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
         } else {
             const uint64_t x = (c == 64) ? 0 : ((xl ^ xr) | (xr << c));
             if (plane) {
-                set_bits<2 * c>(b0, b1, x);
+                set_bits<2 * c>(b0, b0h, b1, x);
             } else {
-                set_bits<2 * c>(a0, a1, x);
+                set_bits<2 * c>(a0, a0h, a1, x);
                 if constexpr (LEV > EAGER_P_TOP) st.ownL = ownp_set(st.ownL, LEV, (uint32_t)lc.p);
             }
         }
@@ -431,7 +453,7 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
         const int src = par * 8 + lc.q;
         st.pm = bperm_f(cpm, par * 8 + 4 * (int)b + (lc.q & 3));  // lanes q >= 4 hold the u=1 candidate metric
         st.ownL = bperm_u(st.ownL, src);
-        a0 = (a0 & 0xFFFFFFFF00000000ull) | bperm_u((uint32_t)a0, src);
+        a0 = bperm_u(a0, src);
         if constexpr (EAGER_L_TOP >= 4) {
             R[2] = bperm_f(R[2], src);
             R[3] = bperm_f(R[3], src);
@@ -559,7 +581,7 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
                 const int slot = rk[u] < Lmax ? rk[u] : 8;
                 uint32_t *rec = xch + slot * 8 + lc.q;
                 rec[0] = st.ownL;
-                rec[RS] = ((uint32_t)a0 & ~1u) | (bme ^ (uint32_t)u);  // bit 0 of a0 belongs to no level; u = 0: my own candidate
+                rec[RS] = (a0 & ~1u) | (bme ^ (uint32_t)u);  // bit 0 of a0 belongs to no level; u = 0: my own candidate
                 int w = 2;
                 rec_put(rec, w, mt[u]);
 #pragma unroll
@@ -572,10 +594,27 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
             }
         }
         wave_sync();
-        const uint32_t *mine = xch + lc.lane;
-        st.ownL = mine[0];
-        const uint32_t op = mine[RS];
-        {
+        uint32_t op;
+        if constexpr (sizeof(T) == 4) {
+            // single reads into the registers that held the old values (see rec_get_into)
+            const uint32_t addr = (uint32_t)(uintptr_t)(xch + lc.lane);
+            op = a0;
+            rec_get_into<0>(st.ownL, addr);
+            rec_get_into<1>(op, addr);
+            rec_get_into<2>(st.pm, addr);
+            constexpr int W0 = 3, W1 = W0 + (int)(LIVE & 1u), W2 = W1 + (int)((LIVE >> 1) & 1u), W3 = W2 + (int)((LIVE >> 2) & 1u);
+            if constexpr (LIVE & 1u) rec_get_into<W0>(st.v[0], addr);
+            if constexpr (LIVE & 2u) rec_get_into<W1>(st.v[1], addr);
+            if constexpr (LIVE & 4u) rec_get_into<W2>(st.v[2], addr);
+            if constexpr (EAGER_L_TOP >= 4) {
+                rec_get_into<W3>(R[2], addr);
+                rec_get_into<W3 + 1>(R[3], addr);
+            }
+            rec_wait();
+        } else {
+            const uint32_t *mine = xch + lc.lane;
+            st.ownL = mine[0];
+            op = mine[RS];
             int w = 2;
             rec_get(mine, w, st.pm);
 #pragma unroll
@@ -587,7 +626,7 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
             }
         }
         wave_sync();
-        a0 = (a0 & 0xFFFFFFFF00000000ull) | (op & ~1u);
+        a0 = op & ~1u;
         return op & 1u;
     }
 
@@ -626,9 +665,9 @@ template <int NLOG, int LMAX, typename T> struct SclReg {
     {
         constexpr int CB = 1 << (LV - 3);
         if (plane) {
-            set_bits<CB>(b0, b1, x);
+            set_bits<CB>(b0, b0h, b1, x);
         } else {
-            set_bits<CB>(a0, a1, x);  // LV <= 6: these sums travel with the path, no owner entry
+            set_bits<CB>(a0, a0h, a1, x);  // LV <= 6: these sums travel with the path, no owner entry
         }
         (void)lc;
     }
@@ -848,9 +887,9 @@ __device__ __forceinline__ void scl_node(SclReg<NLOG, LMAX, T> &d, uint32_t mask
             const uint32_t x = d.node8(d.R[1], m8, lc, surv);
             PROF_ADD(12 + __builtin_popcount(m8));  // categories 12 .. 20: 8-leaf nodes by their number of information bits
             if (h) {
-                d.b0 = (d.b0 & ~(uint64_t)2) | ((uint64_t)x << 1);
+                d.b0 = (d.b0 & ~2u) | (x << 1);
             } else {
-                d.a0 = (d.a0 & ~(uint64_t)2) | ((uint64_t)x << 1);
+                d.a0 = (d.a0 & ~2u) | (x << 1);
             }
         } else {
             if constexpr (LEV - 1 <= 6 && (LEV - 1 <= POLAR_SCL_FROZEN_TOP || LEV - 1 <= POLAR_SCL_SURE_TOP)) {
@@ -971,7 +1010,8 @@ scl_reg_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, co
 
     for (int64_t f = blockIdx.x; f < B; f += gridDim.x) {
         const T *chan_lane = llr + f * N + lc.e;
-        d.a0 = d.a1 = d.b0 = d.b1 = d.r0 = d.r1 = 0;
+        d.a0 = d.a0h = d.b0 = d.b0h = 0u;
+        d.a1 = d.b1 = d.r0 = d.r1 = 0;
         d.st.pm = (T)0;
         d.st.ownL = 0u;
 #pragma unroll
