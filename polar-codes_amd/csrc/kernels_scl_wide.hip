@@ -37,6 +37,17 @@
 
 namespace {
 
+// -DPOLAR_WIDE_STATS: event counts of the ranking, summed over wavefronts (development aid, read by polar_debug_wide_stats)
+#ifdef POLAR_WIDE_STATS
+__device__ unsigned long long g_wide_stats[8];
+#define WIDE_STAT(i)                                                \
+    do {                                                            \
+        if (lane == 0) atomicAdd(&g_wide_stats[i], 1ull);           \
+    } while (0)
+#else
+#define WIDE_STAT(i)
+#endif
+
 __device__ __forceinline__ float wb_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(lane << 2, __float_as_int(v))); }
 __device__ __forceinline__ double wb_f(double v, int lane)
 {
@@ -419,6 +430,9 @@ template <int NLOG, int LMAX, typename T> struct WideDec {
         }
         const bool alive = LMAX == 32 || p < LMAX;
         const Key key = alive ? order_key(cpm) : (Key)0;  // below the key of -inf
+        uint32_t win;
+        WIDE_STAT(0);
+        if (merge_rank(v, key, alive, inv, win)) return settle<WITH_X>(cpm, win, alive);
         const int mypos = h ? p : 32 + p;                  // copies (u = 1) come first in the candidate order
         keys[mypos] = key;
         if (lane < LMAX) inv[lane] = 0xFFFFFFFFu;
@@ -443,7 +457,7 @@ template <int NLOG, int LMAX, typename T> struct WideDec {
         }
         if (cnt < LMAX) inv[cnt] = (uint32_t)lane;
         wave_sync();
-        uint32_t win = inv[p < LMAX ? p : 0];
+        win = inv[p < LMAX ? p : 0];
         const uint64_t claimed = __ballot(cnt < LMAX);
         const uint64_t empty = __ballot(alive && win == 0xFFFFFFFFu);
         if (__popcll(claimed) != LMAX || empty != 0) {
@@ -462,6 +476,12 @@ template <int NLOG, int LMAX, typename T> struct WideDec {
             win = inv[p < LMAX ? p : 0];
         }
         wave_sync();
+        return settle<WITH_X>(cpm, win, alive);
+    }
+
+    // my position takes the candidate in lane `win` (= 2 * path + bit)
+    template <bool WITH_X> __device__ __forceinline__ uint32_t settle(T cpm, uint32_t win, bool alive)
+    {
         const uint32_t b = win & 1u;
         const int par = (int)(win >> 1);
         if (__ballot(alive && par != p) == 0) {  // nothing moves between positions
@@ -471,6 +491,68 @@ template <int NLOG, int LMAX, typename T> struct WideDec {
         }
         take_over<WITH_X>(cpm, par, b);
         return b;
+    }
+
+    static __device__ __forceinline__ Key key_of_lane(Key k, int src)
+    {
+        if constexpr (sizeof(Key) == 4) return (Key)__builtin_amdgcn_readlane((int)k, src);
+        else return ((Key)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k, src);
+    }
+    static __device__ __forceinline__ Key key_from(Key k, int src)
+    {
+        if constexpr (sizeof(Key) == 4) return wb_u(k, src);
+        else return wb_u64(k, src);
+    }
+
+    // Ranking by merging, for a common shape of a full list: the agreeing extensions (the candidate of each path that
+    // follows its LLR's sign) stand in strictly descending order of their metrics by list position, and only a few
+    // disagreeing extensions -- contenders -- reach the metric of the last of them.  The agreeing extension of position p
+    // then has rank p + (contenders above it); a contender has rank (agreeing above it) + (contenders above it), one
+    // wave-wide comparison each; every other disagreeing extension has all L agreeing ones above it and is out.  These are
+    // the counts of larger keys that the ranking over all 64 keys makes when no two keys that matter are equal; an agreeing
+    // pair out of order, any equality with a contender or more than MERGE_MAX contenders returns false, and the caller
+    // ranks the long way.  win: the lane whose candidate takes my position.
+    static constexpr int MERGE_MAX = 6;
+    __device__ __forceinline__ bool merge_rank(T v, Key key, bool alive, uint32_t *inv, uint32_t &win)
+    {
+        const uint32_t a = v < (T)0 ? 1u : 0u;
+        const bool keeper = (uint32_t)h == a;              // my candidate is my path's agreeing extension
+        const Key okey = swap2_key(key);
+        const Key kk = keeper ? key : okey;                // my path's agreeing extension, in both of its lanes
+        const Key kk_next = key_from(kk, lane + 2);
+        const bool in_order = !alive || p == LMAX - 1 || kk > kk_next;
+        const Key bar = key_of_lane(kk, 2 * (LMAX - 1));
+        const bool contender = alive && !keeper && key >= bar;
+        const uint64_t cont = __ballot(contender);
+        if (__ballot(in_order) != ~0ull || __popcll(cont) > MERGE_MAX) return false;
+        WIDE_STAT(1);
+        win = (uint32_t)(2 * p) + a;                       // no contender: every position keeps its path
+        if (cont == 0) return true;
+        int above = 0;                 // contenders above my path's agreeing extension
+        int myrank = 64;               // contenders get theirs below, the other disagreeing extensions are out
+        bool tie = false;
+        for (uint64_t rest = cont; rest != 0; rest &= rest - 1) {
+            WIDE_STAT(2);
+            const int l = __builtin_ctzll(rest);
+            const Key f = key_of_lane(key, l);
+            const uint64_t agree_above = __ballot(alive && kk > f) & 0x5555555555555555ull;
+            const uint64_t cont_above = __ballot(contender && key > f);
+            tie |= __ballot((alive && kk == f) || (contender && key == f && lane != l)) != 0;
+            above += (f > kk) ? 1 : 0;
+            if (lane == l) myrank = __popcll(agree_above) + __popcll(cont_above);
+        }
+        if (tie) return false;
+        if (keeper) myrank = p + above;
+        if (alive && myrank < LMAX) inv[myrank] = (uint32_t)lane;  // ranks 0 .. L-1 are taken once each
+        wave_sync();
+        win = inv[p < LMAX ? p : 0];
+        wave_sync();
+        return true;
+    }
+    static __device__ __forceinline__ Key swap2_key(Key k)
+    {
+        if constexpr (sizeof(Key) == 4) return dpp_mov_u32<0xB1>(k);
+        else return ((Key)dpp_mov_u32<0xB1>((uint32_t)(k >> 32)) << 32) | dpp_mov_u32<0xB1>((uint32_t)k);
     }
 
     // A 2-leaf node; xin = my element of its LLRs, m2 = its rate profile.  Returns my element of its partial sums.
@@ -712,6 +794,18 @@ int launch_wide_l(polar_code *c, const void *llr, int dtype, uint32_t *info_hat,
 
 }  // namespace
 
+#ifdef POLAR_WIDE_STATS
+extern "C" __attribute__((visibility("default"))) int polar_debug_wide_stats(unsigned long long *out, int clear)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wide_stats), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (clear) {
+        unsigned long long z[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_wide_stats), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
 bool scl_wide_supported(const polar_code *c, int dtype, int L, const void *pm, const void *u_hat_all)
 {
     return dispatch_scl(c, dtype, L, pm, u_hat_all) == KF_SCL_WIDE;  // the table of host_tables.cpp says what this kernel serves
@@ -722,11 +816,19 @@ int launch_scl_wide(polar_code *c, const void *llr, int dtype, uint32_t *info_ha
 {
     if (B == 0) return POLAR_OK;
     switch (c->n) {
+#ifdef POLAR_WIDE_DEV_ONE  // development builds: the (512, L = 32) kernels only, seconds to compile
+    case 9:
+        if (L == 32 && dtype == POLAR_F32) return launch_wide_t<9, 32, float>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
+        if (L == 32) return launch_wide_t<9, 32, double>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
+        polar_set_error("development build: L = 32 only");
+        return POLAR_EUNSUPPORTED;
+#else
     case 6: return launch_wide_l<6>(c, llr, dtype, info_hat, pm, u_hat_all, B, L, crc, truth);
     case 7: return launch_wide_l<7>(c, llr, dtype, info_hat, pm, u_hat_all, B, L, crc, truth);
     case 8: return launch_wide_l<8>(c, llr, dtype, info_hat, pm, u_hat_all, B, L, crc, truth);
     case 9: return launch_wide_l<9>(c, llr, dtype, info_hat, pm, u_hat_all, B, L, crc, truth);
     case 10: return launch_wide_l<10>(c, llr, dtype, info_hat, pm, u_hat_all, B, L, crc, truth);
+#endif
     default: polar_set_error("wide list kernel: unsupported length"); return POLAR_EUNSUPPORTED;
     }
 }
