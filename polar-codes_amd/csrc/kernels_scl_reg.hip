@@ -182,10 +182,6 @@ constexpr int EAGER_L_TOP = POLAR_SCL_EAGER_L_TOP;  // so do the LLRs of levels 
 #ifndef POLAR_SCL_SURE_TOP
 #define POLAR_SCL_SURE_TOP 3
 #endif
-// plain decoding (no CRC, no genie): the output stage gathers the best path's information bits only, over all 64 lanes
-#ifndef POLAR_SCL_BEST_GATHER
-#define POLAR_SCL_BEST_GATHER 1
-#endif
 
 
 // -DPOLAR_SCL_PROFILE: per-category wall-clock cycles of the register list decoder, summed over wavefronts
@@ -934,7 +930,6 @@ scl_reg_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, co
     __shared__ uint32_t xchg[RS * XW];
     uint32_t *const surv = xchg;
     uint32_t *const stage = xchg;
-    uint32_t *const passw = xchg + 320;  // bitmap of the list entries that pass the CRC / equal the transmitted word
     constexpr int N = 1 << NLOG;
     // the gather table of the output stage (the CRC remainders stay in global memory); at N = 1024, where LDS decides how
     // many wavefronts a CU holds, it is read from global memory instead
@@ -1066,74 +1061,47 @@ scl_reg_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, co
                 row[wi] = act ? word : 0u;
             }
         }
-        if (POLAR_SCL_BEST_GATHER && info_hat && !crcS && !truth) {
-            // plain decoding: only the best path's information bits leave, and all 64 lanes gather them
+        if (info_hat) {
+            // Only one path's information bits leave.  Plain decoding: the best path's; aided decoding: those of the first
+            // path in metric order that passes (CRC: the information word leaves a zero remainder; genie: it equals the
+            // transmitted word), the best one if none does.  The paths are tried in that order, each gathered by all 64
+            // lanes, so a frame whose best path passes -- nearly every frame above the waterfall -- costs one gather.
             uint32_t *dst = info_hat + f * Kw;
-            const uint64_t bm = __ballot(act && rank == 0);
-            const uint32_t *best = stage + ((__ffsll((unsigned long long)bm) - 1) >> 3) * 32;
-            uint32_t wmine = 0u;
-            pack_bits_group<64>(
-                K, lc.lane, 0,
-                [&](int k) {
-                    const uint32_t a = ASL_LDS ? asl_s[k] : Asl8[k];  // (lane-in-path << 7) | bit
-                    return ((best[(a >> 7) * 4 + ((a >> 5) & 3u)] >> (a & 31u)) & 1u) != 0u;
-                },
-                [&](int wi, uint32_t v) {
-                    if (wi == lc.lane) wmine = v;
-                });
-            if (lc.lane < Kw) dst[lc.lane] = wmine;
-            if (K == 0 && lc.lane == 0) dst[0] = 0u;
-        } else if (info_hat) {
-            uint32_t *dst = info_hat + f * Kw;
-            const uint32_t *mine = stage + lc.p * 32;
-            uint32_t wout[4] = {0u, 0u, 0u, 0u};
-            uint32_t syn = 0u;  // this lane's share of the path's CRC remainder (stays 0 without a CRC)
-            pack_bits_group<8>(
-                K, lc.q, lc.p,
-                [&](int k) {
-                    const uint32_t a = ASL_LDS ? asl_s[k] : Asl8[k];  // (lane-in-path << 7) | bit
-                    const bool bit = ((mine[(a >> 7) * 4 + ((a >> 5) & 3u)] >> (a & 31u)) & 1u) != 0u;
-                    if (crcS && bit) syn ^= crcS[k];
-                    return bit;
-                },
-                [&](int wi, uint32_t v) {
-                    if ((wi & 7) == lc.q) {
-                        if (wi < 8) wout[0] = v;
-                        else if (wi < 16) wout[1] = v;
-                        else if (wi < 24) wout[2] = v;
-                        else wout[3] = v;
-                    }
-                });
-            int sel = 0;
-            if (crcS || truth) {
-                // aided choice: the first path in sorted order that passes, the best one if none does.
-                // CRC: the information word leaves a zero remainder; genie: it equals the transmitted word
+            const int tries = (crcS || truth) ? d.Lcur : 1;
+            uint32_t wmine = 0u, wbest = 0u;
+            for (int r = 0; r < tries; r++) {
+                const uint64_t bm = __ballot(act && rank == r);
+                const uint32_t *cand = stage + ((__ffsll((unsigned long long)bm) - 1) >> 3) * 32;
+                uint32_t syn = 0u;  // this lane's share of the path's CRC remainder
+                wmine = 0u;
+                pack_bits_group<64>(
+                    K, lc.lane, 0,
+                    [&](int k) {
+                        const uint32_t a = ASL_LDS ? asl_s[k] : Asl8[k];  // (lane-in-path << 7) | bit
+                        const bool bit = ((cand[(a >> 7) * 4 + ((a >> 5) & 3u)] >> (a & 31u)) & 1u) != 0u;
+                        if (crcS && bit) syn ^= crcS[k];
+                        return bit;
+                    },
+                    [&](int wi, uint32_t v) {
+                        if (wi == lc.lane) wmine = v;
+                    });
+                if (r == 0) wbest = wmine;
+                bool ok = true;
                 if (truth) {
-                    syn = 0u;
-#pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        if (lc.q + 8 * i < Kw) syn |= wout[i] ^ truth[f * Kw + lc.q + 8 * i];
-                    syn |= partner8_u<2>(syn);
-                    syn |= partner8_u<4>(syn);
-                    syn |= partner8_u<8>(syn);
-                } else {
-                    syn ^= partner8_u<2>(syn);
-                    syn ^= partner8_u<4>(syn);
-                    syn ^= partner8_u<8>(syn);
+                    ok = __ballot(lc.lane < Kw && wmine != truth[f * Kw + lc.lane]) == 0;
+                } else if (crcS) {
+                    syn ^= dpp_mov_u32<0xB1>(syn);   // quad_perm:[1,0,3,2]
+                    syn ^= dpp_mov_u32<0x4E>(syn);   // quad_perm:[2,3,0,1]
+                    syn ^= dpp_mov_u32<0x141>(syn);  // row_half_mirror
+                    syn ^= dpp_mov_u32<0x140>(syn);  // row_mirror: every lane now holds its row's sum
+                    const uint32_t all = (uint32_t)(__builtin_amdgcn_readlane((int)syn, 0) ^ __builtin_amdgcn_readlane((int)syn, 16) ^
+                                                    __builtin_amdgcn_readlane((int)syn, 32) ^ __builtin_amdgcn_readlane((int)syn, 48));
+                    ok = all == 0u;
                 }
-                if (lc.lane == 0) passw[0] = 0u;
-                wave_sync();
-                if (lc.q == 0 && act && syn == 0u) atomicOr(&passw[0], 1u << rank);
-                wave_sync();
-                const uint32_t pass = passw[0];
-                sel = pass ? __ffs(pass) - 1 : 0;
+                if (ok) break;                       // wave-uniform
+                if (r == tries - 1) wmine = wbest;   // none passes
             }
-            const bool best = act && rank == sel;
-            if (best) {
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    if (lc.q + 8 * i < Kw) dst[lc.q + 8 * i] = wout[i];
-            }
+            if (lc.lane < Kw) dst[lc.lane] = wmine;
             if (K == 0 && lc.lane == 0) dst[0] = 0u;
         }
         wave_sync();
