@@ -169,10 +169,10 @@ const DispatchRow TABLE[] = {
     // ---- progressive bit flipping (polar_pbf_decode*, polar_sc_decode_flip); L = largest number of simultaneous flips
     {DQ_OP_PBF, KF_PBF_REG, "pbf_reg_kernel<", F32 | F64, 5, 10, LM(1), 1, DQ_OUT_INFO, 0, DQ_CRC, DQ_FORCE_LDS | DQ_FLIP_LIST,
      "SC runs in registers, four flip candidates per wavefront, single flips"},
-    {DQ_OP_PBF, KF_PBF_REG, "pbf_reg_kernel<", F32 | F64, 5, 10, LM(2), 1, DQ_OUT_INFO, 0, DQ_CRC | DQ_SPLIT, DQ_FORCE_LDS | DQ_FLIP_LIST,
-     "the same for the two-flip search in pieces"},
+    {DQ_OP_PBF, KF_PBF_REG, "pbf_reg_kernel<", F32 | F64, 5, 10, LM(2, 3), 1, DQ_OUT_INFO, 0, DQ_CRC | DQ_SPLIT, DQ_FORCE_LDS | DQ_FLIP_LIST,
+     "the same for the two- and three-flip searches in pieces"},
     {DQ_OP_PBF, KF_PBF_LDS, "pbf_decode_kernel<", F32 | F64, 0, 12, 0, 0, ALL_SC, 0, 0, 0,
-     "one wavefront per frame, LDS-staged SC runs: three flips, N > 1024, flip lists, side outputs"},
+     "one wavefront per frame, LDS-staged SC runs: N > 1024, flip lists, side outputs, searches not worked on in pieces"},
     // ---- the SC Monte-Carlo loop of polar_mc_run
     {DQ_OP_MC_SC, KF_MC_FUSED, "sc_static_mc_kernel", F32, 7, 10, 0, 1, 0, 0, DQ_FAST | DQ_SPECIALISED | DQ_INTERIOR_K, DQ_CRC | DQ_FORCE_GENERIC,
      "draw, encode, channel, decode and count in one kernel, no LLR buffer"},

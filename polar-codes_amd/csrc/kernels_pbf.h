@@ -29,6 +29,10 @@ template <typename T> struct PBFParams {
     unsigned long long *nrows2;
     uint16_t *order_rec;
     unsigned long long *best;
+    // split three-flip search: per frame the smallest successful triple found so far (triple_key in kernels_pbf_reg.hip), and
+    // per code position the number of candidates two levels below a flip there (sum of the candidate counts of its candidates)
+    unsigned long long *best3;
+    const int32_t *crit_sum;
     int64_t B;
     int N, n, Nw, K, Kw, nS0, maxS, max_level;
 };

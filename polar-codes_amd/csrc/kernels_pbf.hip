@@ -488,6 +488,8 @@ static int launch_pbf_t(polar_code *c, const void *llr, const uint32_t *rows, co
     p.nrows2 = split ? split->ctr + 1 : nullptr;
     p.order_rec = split ? split->order_rec : nullptr;
     p.best = split ? split->best : nullptr;
+    p.best3 = split ? split->best3 : nullptr;
+    p.crit_sum = c->d_crit_sum;
     p.B = B;
     p.N = c->N;
     p.n = c->n;
@@ -554,8 +556,8 @@ int launch_pbf(polar_code *c, const void *llr, int dtype, const uint32_t *rows, 
         polar_set_error("flip decoder: N=%d exceeds the supported maximum of 4096", c->N);
         return POLAR_EUNSUPPORTED;
     }
-    if (split && (max_level != 2 || flips_in || u_hat || dec_llr || !crc)) {
-        polar_set_error("flip decoder: the split search serves two-flip CRC searches without side outputs only");
+    if (split && ((max_level != 2 && !(max_level == 3 && split->best3 && pbf_split3_supported(c))) || flips_in || u_hat || dec_llr || !crc)) {
+        polar_set_error("flip decoder: the split search serves two-flip (and, in registers, three-flip) CRC searches without side outputs only");
         return POLAR_EINVAL;
     }
     if (dtype == POLAR_F32)

@@ -52,10 +52,10 @@ __device__ __forceinline__ uint32_t sub_node_fm(T v, uint32_t mask, uint32_t fm,
 }
 
 // node idx of level LEV >= 5: the loop nest of decode_node without short-cuts, flips at code positions fl0 / fl1
-// (-1: none; they may differ from row to row)
+// / fl2 (-1: none; they may differ from row to row)
 template <int LEV, bool DL, typename Dec>
 __device__ __forceinline__ void flip_walk(Dec &d, uint32_t maskv, const typename Dec::value_type *chan_lane, uint32_t idx, int plane,
-                                          const RowConst &rc, int fl0, int fl1, typename Dec::value_type *dl_lane, int sub)
+                                          const RowConst &rc, int fl0, int fl1, int fl2, typename Dec::value_type *dl_lane, int sub)
 {
     typedef typename Dec::value_type T;
 #pragma nounroll
@@ -66,7 +66,8 @@ __device__ __forceinline__ void flip_walk(Dec &d, uint32_t maskv, const typename
         if constexpr (LEV - 1 == 4) {
             const uint32_t mw = (uint32_t)__builtin_amdgcn_readlane((int)maskv, (int)(cidx >> 1));
             const uint32_t m16 = (mw >> (16 * (cidx & 1))) & 0xFFFFu;
-            const uint32_t fm = ((uint32_t)(fl0 >> 4) == cidx ? 1u << (fl0 & 15) : 0u) | ((uint32_t)(fl1 >> 4) == cidx ? 1u << (fl1 & 15) : 0u);
+            const uint32_t fm = ((uint32_t)(fl0 >> 4) == cidx ? 1u << (fl0 & 15) : 0u) | ((uint32_t)(fl1 >> 4) == cidx ? 1u << (fl1 & 15) : 0u) |
+                                ((uint32_t)(fl2 >> 4) == cidx ? 1u << (fl2 & 15) : 0u);
             T keep = 0;
             const uint32_t x = sub_node_fm<16, 0, DL>(d.R[1], m16, fm, rc, sub, keep);
             if constexpr (DL) {
@@ -75,13 +76,21 @@ __device__ __forceinline__ void flip_walk(Dec &d, uint32_t maskv, const typename
             if (h) d.ps1 = (d.ps1 & ~(ps_t)2) | ((ps_t)x << 1);
             else d.ps0 = (d.ps0 & ~(ps_t)2) | ((ps_t)x << 1);
         } else {
-            flip_walk<LEV - 1, DL>(d, maskv, chan_lane, cidx, (int)h, rc, fl0, fl1, dl_lane, sub);
+            flip_walk<LEV - 1, DL>(d, maskv, chan_lane, cidx, (int)h, rc, fl0, fl1, fl2, dl_lane, sub);
         }
     }
     d.template combine<LEV>(plane);
 }
 
-enum { PBF_SINGLES = 0, PBF_PAIRS = 1, PBF_FINISH = 2 };
+enum { PBF_SINGLES = 0, PBF_PAIRS = 1, PBF_FINISH = 2, PBF_TRIPLES = 3, PBF_FINISH3 = 4 };
+
+// The smallest successful triple a frame has so far: ranks of the first, second and third flip (10 bits each from bit 54,
+// 44, 34 down), then the three flipped positions (10 bits each from bit 20, 10, 0); all ones = none.  N <= 1024 here.
+__device__ __forceinline__ unsigned long long triple_key(int a, int b, int c, int fl0, int fl1, int fl2)
+{
+    return ((unsigned long long)a << 54) | ((unsigned long long)b << 44) | ((unsigned long long)c << 34) | ((unsigned long long)fl0 << 20) |
+           ((unsigned long long)fl1 << 10) | (unsigned long long)fl2;
+}
 
 template <typename T, int NLOG> struct PbfRegWave {
     static constexpr int N = 1 << NLOG;
@@ -96,6 +105,7 @@ template <typename T, int NLOG> struct PbfRegWave {
     T *dl;                  // N decision LLRs of row 0's last ranking run
     double *Mv;             // maxS ranking keys
     uint16_t *order;        // maxS ranked candidates
+    uint16_t *order2;       // maxS ranked candidates of the level below (three flips)
     uint32_t *misc;
     const T *chan_lane;
     int64_t f;
@@ -118,14 +128,14 @@ template <typename T, int NLOG> struct PbfRegWave {
     }
     // one run per row with flips fl0 (all rows) and fl1 (this row's).  DL: the run's decision LLRs rank the next level's
     // candidates; such a run is the same in every row, and row 0 records them.
-    template <bool DL> __device__ __forceinline__ void walk(int fl0, int fl1)
+    template <bool DL, bool THREE = false> __device__ __forceinline__ void walk(int fl0, int fl1, int fl2 = -1)
     {
         d.ps0 = d.ps1 = 0;
         d.root = 0;
-        flip_walk<NLOG, DL>(d, maskv, chan_lane, 0u, 0, rc, fl0, fl1, DL && grp == 0 ? dl + sub : (T *)nullptr, sub);
+        flip_walk<NLOG, DL>(d, maskv, chan_lane, 0u, 0, rc, fl0, fl1, THREE ? fl2 : -1, DL && grp == 0 ? dl + sub : (T *)nullptr, sub);
         if constexpr (DL) wave_sync();
     }
-    __device__ __forceinline__ void run_ranking(int fl0) { walk<true>(fl0, -1); }
+    __device__ __forceinline__ void run_ranking(int fl0, int fl1 = -1) { walk<true>(fl0, fl1); }
     // information words and CRC of the rows' last runs; true in the lanes of the rows whose CRC holds
     __device__ __forceinline__ bool test()
     {
@@ -145,8 +155,14 @@ template <typename T, int NLOG> struct PbfRegWave {
         walk<false>(fl0, fl1);
         return test();
     }
+    __device__ __forceinline__ bool run_tested3(int fl0, int fl1, int fl2)
+    {
+        walk<false, true>(fl0, fl1, fl2);
+        return test();
+    }
     // candidates src[0..cnt) ranked by |decision LLR| / sqrt(mu), ascending, equal keys in list order
-    __device__ __forceinline__ void rank(const int32_t *src, int cnt)
+    __device__ __forceinline__ void rank(const int32_t *src, int cnt) { rank(src, cnt, order); }
+    __device__ __forceinline__ void rank(const int32_t *src, int cnt, uint16_t *dst)
     {
         for (int j = lane; j < cnt; j += 64) {
             const int i = src[j];
@@ -160,7 +176,7 @@ template <typename T, int NLOG> struct PbfRegWave {
                 const double mi = Mv[i];
                 r += (mi < mj || (mi == mj && i < j)) ? 1 : 0;
             }
-            order[r] = (uint16_t)src[j];
+            dst[r] = (uint16_t)src[j];
         }
         wave_sync();
     }
@@ -173,7 +189,7 @@ template <typename T, int NLOG> struct PbfRegWave {
             if (sub + 16 < p.Kw) dst[sub + 16] = w_hi;
         }
     }
-    __device__ __forceinline__ void store_side(int nruns, bool ok, int s0, int s1)
+    __device__ __forceinline__ void store_side(int nruns, bool ok, int s0, int s1, int s2 = -1)
     {
         if (lane == 0) {
             if (p.runs) p.runs[f] = nruns;
@@ -181,7 +197,7 @@ template <typename T, int NLOG> struct PbfRegWave {
             if (p.last_seq) {
                 p.last_seq[f * 3] = s0;
                 p.last_seq[f * 3 + 1] = s1;
-                p.last_seq[f * 3 + 2] = -1;
+                p.last_seq[f * 3 + 2] = s2;
             }
         }
     }
@@ -202,6 +218,33 @@ template <typename T, int NLOG> struct PbfRegWave {
             }
         }
         return -1;
+    }
+    // the same one level down: four candidates of order2[] at a time, each together with fl0 and fl1
+    template <typename Stop> __device__ __forceinline__ int try_ranked3(int fl0, int fl1, int cnt, Stop stop, int &flip)
+    {
+        for (int c0 = 0; c0 < cnt; c0 += 4) {
+            if (stop(c0)) return -2;
+            const int mine = c0 + grp;
+            const int fl = mine < cnt ? (int)order2[mine] : -1;
+            const bool ok = run_tested3(fl0, fl1, fl) && mine < cnt;
+            const uint64_t rows = __ballot(ok);
+            if (rows) {
+                const int g = (__ffsll((unsigned long long)rows) - 1) >> 4;
+                flip = __builtin_amdgcn_readlane(fl, 16 * g);
+                return c0 + g;
+            }
+        }
+        return -1;
+    }
+    __device__ __forceinline__ int crit_count(int fl) const { return p.crit_off[fl + 1] - p.crit_off[fl]; }
+    // candidates one level below the flip at position fl, summed over the level in between
+    __device__ __forceinline__ int crit_below(int fl) const { return p.crit_sum[fl]; }
+    template <typename F> __device__ __forceinline__ int wave_sum(int n, F term)
+    {
+        int v = 0;
+        for (int j = lane; j < n; j += 64) v += term(j);
+        for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+        return v;
     }
 };
 
@@ -234,11 +277,13 @@ __global__ void __launch_bounds__(64 * PBF_WAVES, sizeof(T) == 8 ? 2 : 4) pbf_re
     w.ctab = ctab_s;
     w.crc = crc_s;
     w.misc = misc_s + wave;
-    const size_t per_wave = (size_t)N * sizeof(T) + (size_t)p.maxS * 8 + (((size_t)p.maxS * 2 + 15) & ~(size_t)15);
+    const size_t ord = ((size_t)p.maxS * 2 + 15) & ~(size_t)15;
+    const size_t per_wave = (size_t)N * sizeof(T) + (size_t)p.maxS * 8 + 2 * ord;
     unsigned char *mine = dyn + 4096 + (size_t)wave * per_wave;
     w.dl = reinterpret_cast<T *>(mine);
     w.Mv = reinterpret_cast<double *>(mine + (size_t)N * sizeof(T));
     w.order = reinterpret_cast<uint16_t *>(mine + (size_t)N * sizeof(T) + (size_t)p.maxS * 8);
+    w.order2 = reinterpret_cast<uint16_t *>(mine + (size_t)N * sizeof(T) + (size_t)p.maxS * 8 + ord);
     auto never = [](int) { return false; };
 
     if constexpr (MODE == PBF_SINGLES) {
@@ -277,6 +322,7 @@ __global__ void __launch_bounds__(64 * PBF_WAVES, sizeof(T) == 8 ? 2 : 4) pbf_re
                 if (w.lane == 0) {
                     p.rows2[slot] = (uint32_t)w.f;
                     p.best[slot] = ~0ull;
+                    if (p.best3) p.best3[slot] = ~0ull;
                 }
             }
             wave_sync();
@@ -302,6 +348,119 @@ __global__ void __launch_bounds__(64 * PBF_WAVES, sizeof(T) == 8 ? 2 : 4) pbf_re
             if (r >= 0 && w.lane == 0)
                 atomicMin(p.best + slot, ((((unsigned long long)a << 16) | (unsigned long long)r) << 32) | ((unsigned long long)fl0 << 16) |
                                              (unsigned long long)fl1);
+        }
+    } else if constexpr (MODE == PBF_TRIPLES) {
+        // Third level, on the frames no pair helped.  Work item = (first flip's rank a, frame): the run with the first flip
+        // alone ranks the second flips; for each of them in rank order the run with both ranks the third flips, which are
+        // tested four at a time.  The reference stops at the first success in lexicographic order of the three ranks
+        // (cn/polarCode.py:1596-1626 walks level 3's nodes in the order level 2 appended them); here the smallest successful
+        // triple wins through a 64-bit atomicMin per frame and what can no longer win is skipped.
+        const uint64_t n2 = *p.nrows2;
+        const uint64_t items = n2 * (uint64_t)p.nS0;
+        for (;;) {
+            const uint64_t wi = w.next_item(p.work);
+            if (wi >= items) break;
+            const uint32_t a = (uint32_t)(wi / n2), slot = (uint32_t)(wi % n2);
+            if (load_best(p.best + slot) != ~0ull) continue;  // a pair passed
+            if ((load_best(p.best3 + slot) >> 54) < a) continue;
+            const int fl0 = p.order_rec[(size_t)slot * p.nS0 + a];
+            const int cnt1 = w.crit_count(fl0);
+            if (cnt1 == 0 || w.crit_below(fl0) == 0) continue;
+            w.frame((int64_t)p.rows2[slot]);
+            w.run_ranking(fl0);
+            w.rank(p.crit_idx + p.crit_off[fl0], cnt1, w.order);
+            for (int b = 0; b < cnt1; b++) {
+                if ((load_best(p.best3 + slot) >> 44) < (((unsigned long long)a << 10) | (unsigned long long)b)) break;
+                const int fl1 = w.order[b];
+                const int cnt2 = w.crit_count(fl1);
+                if (cnt2 == 0) continue;
+                w.run_ranking(fl0, fl1);
+                w.rank(p.crit_idx + p.crit_off[fl1], cnt2, w.order2);
+                int fl2 = -1;
+                const int r = w.try_ranked3(
+                    fl0, fl1, cnt2,
+                    [&](int c) {
+                        return (load_best(p.best3 + slot) >> 34) <
+                               (((unsigned long long)a << 20) | ((unsigned long long)b << 10) | (unsigned long long)c);
+                    },
+                    fl2);
+                if (r >= 0) {
+                    if (w.lane == 0) atomicMin(p.best3 + slot, triple_key((int)a, b, r, fl0, fl1, fl2));
+                    break;
+                }
+                if (r == -2) break;
+            }
+        }
+    } else if constexpr (MODE == PBF_FINISH3) {
+        // Outputs of the frames the pair and triple searches worked on: the winner's run, or -- nothing passed -- the last
+        // tested run of the whole search in the reference's order; the number of tested runs follows from the candidate counts.
+        const uint64_t n2 = *p.nrows2;
+        for (uint64_t slot = (uint64_t)blockIdx.x * PBF_WAVES + wave; slot < n2; slot += (uint64_t)gridDim.x * PBF_WAVES) {
+            const unsigned long long best = p.best[slot], best3 = p.best3[slot];
+            const bool found2 = best != ~0ull, found3 = !found2 && best3 != ~0ull;
+            const uint16_t *rec = p.order_rec + (size_t)slot * p.nS0;
+            const int a2 = (int)(best >> 48), b2 = (int)((best >> 32) & 0xFFFFu);
+            const int a3 = (int)(best3 >> 54), b3 = (int)((best3 >> 44) & 1023u), c3 = (int)((best3 >> 34) & 1023u);
+            // tested runs of level 2 (before the winning pair's first flip, or all of them), of level 3 before the winning
+            // triple's first flip (or all of them); the last first flip with pairs / with triples below it
+            const int upto2 = found2 ? a2 : p.nS0, upto3 = found2 ? 0 : found3 ? a3 : p.nS0;
+            int before2 = 0, before3 = 0, last2 = -1, last3 = -1;
+            for (int j = w.lane; j < p.nS0; j += 64) {
+                const int fl = rec[j];
+                const int cnt = w.crit_count(fl), below = w.crit_below(fl);
+                if (j < upto2) before2 += cnt;
+                if (j < upto3) before3 += below;
+                if (cnt > 0) last2 = j;
+                if (below > 0) last3 = j;
+            }
+            for (int off = 1; off < 64; off <<= 1) {
+                before2 += __shfl_xor(before2, off, 64);
+                before3 += __shfl_xor(before3, off, 64);
+                last2 = max(last2, __shfl_xor(last2, off, 64));
+                last3 = max(last3, __shfl_xor(last3, off, 64));
+            }
+            if (!found2 && !found3 && last2 < 0) continue;  // no pair exists (so no triple either): the single-flip level's outputs stand
+            w.frame((int64_t)p.rows2[slot]);
+            int fl0, fl1, fl2 = -1, nruns = 1 + p.nS0 + before2;
+            if (found2) {
+                fl0 = (int)((best >> 16) & 0xFFFFu);
+                fl1 = (int)(best & 0xFFFFu);
+                nruns += b2 + 1;
+            } else if (found3 || last3 >= 0) {
+                // the second flips of the (winning / last) first flip in rank order: the tested runs under those before the
+                // winner, or the last of them that has third flips
+                fl0 = found3 ? (int)((best3 >> 20) & 1023u) : (int)rec[last3];
+                const int cnt1 = w.crit_count(fl0);
+                w.run_ranking(fl0);
+                w.rank(p.crit_idx + p.crit_off[fl0], cnt1, w.order);
+                nruns += before3;
+                if (found3) {
+                    fl1 = (int)((best3 >> 10) & 1023u);
+                    fl2 = (int)(best3 & 1023u);
+                    nruns += w.wave_sum(b3, [&](int j) { return w.crit_count((int)w.order[j]); }) + c3 + 1;
+                } else {
+                    int bl = -1;
+                    for (int j = w.lane; j < cnt1; j += 64)
+                        if (w.crit_count((int)w.order[j]) > 0) bl = j;
+                    for (int off = 1; off < 64; off <<= 1) bl = max(bl, __shfl_xor(bl, off, 64));
+                    fl1 = w.order[bl];
+                    const int cnt2 = w.crit_count(fl1);
+                    w.run_ranking(fl0, fl1);
+                    w.rank(p.crit_idx + p.crit_off[fl1], cnt2, w.order2);
+                    fl2 = w.order2[cnt2 - 1];
+                }
+            } else {
+                // no triple exists: the last pair of level 2 was the last tested run
+                fl0 = rec[last2];
+                const int cnt = w.crit_count(fl0);
+                w.run_ranking(fl0);
+                w.rank(p.crit_idx + p.crit_off[fl0], cnt, w.order);
+                fl1 = w.order[cnt - 1];
+            }
+            w.run_tested3(fl0, fl1, fl2);  // the same run in every row
+            w.store_words(0);
+            w.store_side(nruns, found2 || found3, fl0, fl1, fl2);
+            wave_sync();
         }
     } else {
         const uint64_t n2 = *p.nrows2;
@@ -349,7 +508,7 @@ template <typename T, int NLOG>
 int launch_pbf_reg_t(polar_code *c, PBFParams<T> &p, int64_t B, const PbfSplit *split, int max_level)
 {
     polar_ctx *ctx = c->ctx;
-    const size_t per_wave = (size_t)c->N * sizeof(T) + (size_t)p.maxS * 8 + (((size_t)p.maxS * 2 + 15) & ~(size_t)15);
+    const size_t per_wave = (size_t)c->N * sizeof(T) + (size_t)p.maxS * 8 + 2 * (((size_t)p.maxS * 2 + 15) & ~(size_t)15);
     const size_t lds = 4096 + PBF_WAVES * per_wave;
     auto k0 = pbf_reg_kernel<T, NLOG, PBF_SINGLES>;
     auto k1 = pbf_reg_kernel<T, NLOG, PBF_PAIRS>;
@@ -367,12 +526,22 @@ int launch_pbf_reg_t(polar_code *c, PBFParams<T> &p, int64_t B, const PbfSplit *
         p.max_level = 2;
         hipLaunchKernelGGL(k1, dim3((unsigned)resident), dim3(64 * PBF_WAVES), lds, ctx->stream, p, (const uint32_t *)c->d_maskw, (const uint32_t *)c->d_ctab);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(k2, dim3((unsigned)grid), dim3(64 * PBF_WAVES), lds, ctx->stream, p, (const uint32_t *)c->d_maskw, (const uint32_t *)c->d_ctab);
+        if (max_level == 3) {
+            auto k3 = pbf_reg_kernel<T, NLOG, PBF_TRIPLES>;
+            auto k4 = pbf_reg_kernel<T, NLOG, PBF_FINISH3>;
+            p.work = split->ctr + 2;
+            p.max_level = 3;
+            hipLaunchKernelGGL(k3, dim3((unsigned)resident), dim3(64 * PBF_WAVES), lds, ctx->stream, p, (const uint32_t *)c->d_maskw, (const uint32_t *)c->d_ctab);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(k4, dim3((unsigned)grid), dim3(64 * PBF_WAVES), lds, ctx->stream, p, (const uint32_t *)c->d_maskw, (const uint32_t *)c->d_ctab);
+        } else {
+            hipLaunchKernelGGL(k2, dim3((unsigned)grid), dim3(64 * PBF_WAVES), lds, ctx->stream, p, (const uint32_t *)c->d_maskw, (const uint32_t *)c->d_ctab);
+        }
         HIP_TRY(hipGetLastError());
     }
     const float ms = tm.stop();
     snprintf(c->last.kernel, sizeof(c->last.kernel), "pbf_reg_kernel<%s,%d>/T%d%s", sizeof(T) == 4 ? "float" : "double", NLOG, max_level,
-             split ? "+pairs" : "");
+             !split ? "" : max_level == 3 ? "+pairs+triples" : "+pairs");
     c->last.lanes_per_frame = 64;
     c->last.lds_bytes_per_block = (int)lds + 4 * PBF_WAVES * SC_STAGE_WORDS + 1024;
     c->last.block_threads = 64 * PBF_WAVES;
@@ -396,7 +565,7 @@ template <typename T> int launch_pbf_reg_n(polar_code *c, PBFParams<T> &p, int64
 
 }  // namespace
 
-// The register search serves the CRC-driven search over a list of failed frames with one flip, or two flips in pieces.
+// The register search serves the CRC-driven search over a list of failed frames with one flip, or two or three flips in pieces.
 bool pbf_reg_supported(const polar_code *c, const uint32_t *rows, const int32_t *flips_in, int max_level, bool crc, const void *u_hat,
                        const void *dec_llr, const PbfSplit *split)
 {
@@ -404,6 +573,13 @@ bool pbf_reg_supported(const polar_code *c, const uint32_t *rows, const int32_t 
     // call without that list counts as a call with a flip list
     DispatchQuery q{DQ_OP_PBF, c->n, c->K, 0, max_level, DQ_OUT_INFO | (u_hat ? DQ_OUT_UHAT : 0) | (dec_llr ? DQ_OUT_DECLLR : 0),
                     (crc ? DQ_CRC : 0) | (split ? DQ_SPLIT : 0) | ((flips_in || !rows) ? DQ_FLIP_LIST : 0) | dq_switch_flags("POLAR_PBF_KERNEL")};
+    const int row = dispatch_select(q);
+    return row >= 0 && dispatch_table(nullptr)[row].family == KF_PBF_REG;
+}
+
+bool pbf_split3_supported(const polar_code *c)
+{
+    DispatchQuery q{DQ_OP_PBF, c->n, c->K, 0, 3, DQ_OUT_INFO, DQ_CRC | DQ_SPLIT | dq_switch_flags("POLAR_PBF_KERNEL")};
     const int row = dispatch_select(q);
     return row >= 0 && dispatch_table(nullptr)[row].family == KF_PBF_REG;
 }

@@ -258,7 +258,7 @@ extern "C" int polar_code_destroy(polar_code *c)
                       c->d_crcE, c->d_crcS, c->d_pid16};
     for (uint32_t *p : ps)
         if (p) (void)hipFree(p);
-    void *qs[] = {c->d_S0, c->d_crit_off, c->d_crit_idx, c->d_sqrt_mu};
+    void *qs[] = {c->d_S0, c->d_crit_off, c->d_crit_idx, c->d_crit_sum, c->d_sqrt_mu};
     for (void *p : qs)
         if (p) (void)hipFree(p);
     if (c->static_mod) (void)hipModuleUnload(c->static_mod);
@@ -726,7 +726,13 @@ static int ensure_flip_tables(polar_code *c, bool need_lists)
             }
             off[i + 1] = (int32_t)idx.size();
         }
+        // candidates two levels below a flip at position i (what the three-flip search tests under it)
+        std::vector<int32_t> below(c->N, 0);
+        for (int i = 0; i < c->N; i++)
+            for (int32_t k = off[i]; k < off[i + 1]; k++) below[i] += off[idx[k] + 1] - off[idx[k]];
         if (idx.empty()) idx.push_back(0);
+        HIP_TRY(hipMalloc((void **)&c->d_crit_sum, below.size() * 4));
+        HIP_TRY(hipMemcpy(c->d_crit_sum, below.data(), below.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void **)&c->d_crit_off, off.size() * 4));
         HIP_TRY(hipMalloc((void **)&c->d_crit_idx, idx.size() * 4));
         HIP_TRY(hipMemcpy(c->d_crit_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
@@ -746,7 +752,7 @@ static int pbf_device_on(polar_code *c, const void *dl, int dtype, int max_level
     polar_ctx *ctx = c->ctx;
     int rc;
     HIP_TRY(hipMemsetAsync(ctr, 0, 16, ctx->stream));
-    if (split) HIP_TRY(hipMemsetAsync(split->ctr, 0, 16, ctx->stream));
+    if (split) HIP_TRY(hipMemsetAsync(split->ctr, 0, 24, ctx->stream));
     if ((rc = launch_sc_decode(c, dl, dtype, wi, nullptr, nullptr, nb, POLAR_SC_FAST))) return rc;
     if ((rc = launch_crc_filter(c, wi, rows, ctr + 1, d_runs, d_ok, d_last, nb))) return rc;
     if (max_level >= 1)
@@ -755,8 +761,8 @@ static int pbf_device_on(polar_code *c, const void *dl, int dtype, int max_level
     return rc;
 }
 
-// Frames per pass of the two-flip search: bounds its workspace (a frame that fails every single flip keeps
-// 12 + 2 nS0 bytes) whatever the batch size.
+// Frames per pass of the two- and three-flip searches: bounds their workspace (a frame that fails every single flip keeps
+// 20 + 2 nS0 bytes) whatever the batch size.
 static const int64_t PBF_SPLIT_FRAMES = (int64_t)1 << 18;
 
 static int pbf_device(polar_code *c, const void *dl, int dtype, int max_level, uint32_t *wi, int32_t *d_runs, uint8_t *d_ok,
@@ -765,26 +771,30 @@ static int pbf_device(polar_code *c, const void *dl, int dtype, int max_level, u
     polar_ctx *ctx = c->ctx;
     int rc;
     if ((rc = ensure_flip_tables(c, max_level >= 2))) return rc;
-    if ((rc = ctx->flip_rows.reserve(nb * 4)) || (rc = ctx->flip_ctr.reserve(32))) return rc;
+    if ((rc = ctx->flip_rows.reserve(nb * 4)) || (rc = ctx->flip_ctr.reserve(64))) return rc;
     uint32_t *rows = ctx->flip_rows.as<uint32_t>();
     unsigned long long *ctr = ctx->flip_ctr.as<unsigned long long>();
     const char *sw = polar_switch("POLAR_PBF_SPLIT");
     const bool whole_frames = sw && atoi(sw) == 0;
-    if (max_level != 2 || whole_frames) return pbf_device_on(c, dl, dtype, max_level, wi, d_runs, d_ok, d_last, nb, rows, ctr);
-    // two flips: the second level is worked on in (frame, first flip) pieces, PBF_SPLIT_FRAMES frames at a time
+    // two flips: the second level is worked on in (frame, first flip) pieces, PBF_SPLIT_FRAMES frames at a time; three flips
+    // the same way where the register search serves them (a frame that needs the third level costs 10^5 runs: one wavefront
+    // per frame would hold the whole launch for seconds)
+    const bool split3 = max_level == 3 && pbf_split3_supported(c);
+    if ((max_level != 2 && !split3) || whole_frames) return pbf_device_on(c, dl, dtype, max_level, wi, d_runs, d_ok, d_last, nb, rows, ctr);
     const int64_t cap = std::min(nb, PBF_SPLIT_FRAMES);
     const size_t rec = (size_t)std::max(c->nS0, 1) * 2;
-    const size_t off_best = ((size_t)cap * 4 + 255) & ~(size_t)255, off_rec = off_best + (size_t)cap * 8;
+    const size_t off_best = ((size_t)cap * 4 + 255) & ~(size_t)255, off_best3 = off_best + (size_t)cap * 8, off_rec = off_best3 + (size_t)cap * 8;
     if ((rc = ctx->flip_pairs.reserve(off_rec + (size_t)cap * rec))) return rc;
     PbfSplit sp;
     sp.ctr = ctr + 2;
     sp.rows2 = ctx->flip_pairs.as<uint32_t>();
     sp.best = reinterpret_cast<unsigned long long *>(ctx->flip_pairs.as<char>() + off_best);
+    sp.best3 = split3 ? reinterpret_cast<unsigned long long *>(ctx->flip_pairs.as<char>() + off_best3) : nullptr;
     sp.order_rec = reinterpret_cast<uint16_t *>(ctx->flip_pairs.as<char>() + off_rec);
     const size_t es = llr_size(dtype);
     for (int64_t b0 = 0; b0 < nb; b0 += cap) {
         const int64_t m = std::min(cap, nb - b0);
-        if ((rc = pbf_device_on(c, (const char *)dl + b0 * c->N * es, dtype, 2, wi + b0 * c->Kw, d_runs ? d_runs + b0 : nullptr,
+        if ((rc = pbf_device_on(c, (const char *)dl + b0 * c->N * es, dtype, max_level, wi + b0 * c->Kw, d_runs ? d_runs + b0 : nullptr,
                                 d_ok ? d_ok + b0 : nullptr, d_last ? d_last + 3 * b0 : nullptr, m, rows, ctr, &sp)))
             return rc;
     }

@@ -85,7 +85,7 @@ struct polar_code {
     uint32_t *d_crcE = nullptr;    // K - crc_w words: CRC bits (bit j = j-th appended bit) contributed by message bit k
     uint32_t *d_crcS = nullptr;    // K words: remainder contributed by bit k of the K-bit word (message + CRC)
     // bit flipping: level-0 candidates, candidates after a flip at each position (CSR), sqrt of the mean LLRs
-    int32_t *d_S0 = nullptr, *d_crit_off = nullptr, *d_crit_idx = nullptr;
+    int32_t *d_S0 = nullptr, *d_crit_off = nullptr, *d_crit_idx = nullptr, *d_crit_sum = nullptr;
     double *d_sqrt_mu = nullptr;
     int nS0 = 0, maxS = 0;
     bool have_mu = false, have_crit = false;
@@ -136,11 +136,14 @@ int launch_count_errors(polar_code *c, const uint32_t *info, const uint32_t *hat
 // that failed every single flip} (zero at launch), rows2 / best one entry per frame that may get there, order_rec
 // nS0 entries per such frame.
 struct PbfSplit {
-    unsigned long long *ctr;
+    unsigned long long *ctr;       // work counter of the pair search, number of frames handed over, work counter of the triple search
     uint32_t *rows2;
     unsigned long long *best;
     uint16_t *order_rec;
+    unsigned long long *best3;     // three flips only
 };
+// the three-flip search in pieces exists in the register search only (the dispatch table's row for it)
+bool pbf_split3_supported(const polar_code *c);
 int launch_pbf(polar_code *c, const void *llr, int dtype, const uint32_t *rows, const unsigned long long *nrows_dev,
                unsigned long long *work, const int32_t *flips_in, int max_level, bool crc, uint32_t *info_hat, uint32_t *u_hat,
                void *dec_llr, int32_t *runs, uint8_t *crc_ok, int32_t *last_seq, int64_t B, const PbfSplit *split = nullptr);

@@ -209,6 +209,48 @@ def test_gpu_pbf_two_flips_in_pieces_equals_whole_frame_search(N, K, poly, nfr, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,K,poly,nfr,snr,dtype", [(64, 30, 0x107, 3000, 1.0, 0), (128, 72, 0x107, 1500, 1.5, 1), (256, 140, 0x1621, 300, 1.5, 0),
+                                                     (32, 20, 0x107, 2000, 0.0, 1)])
+def test_gpu_pbf_three_flips_in_pieces_equals_whole_frame_search(N, K, poly, nfr, snr, dtype, monkeypatch):
+    """Three flips: the search worked on in (frame, first flip) pieces by many wavefronts, SC runs in registers, gives the
+    runs, flips, CRC flags and bits of the depth-first search one wavefront makes per frame (which the oracle tests and
+    the reference's vectors pin): frames that pass with one, two and three flips and frames that never pass."""
+    import torch
+
+    mask, mu = pcf.degaBuild(N, K, 2.0), pcf.GA(N, K, 2.0)
+    w = poly.bit_length() - 1
+    n0 = n0_ebn0(snr, (K - w) / N)
+    code = _native.Code(_native.default_ctx(), mask)
+    code.set_crc(poly)
+    code.set_reliability(mu)
+    npdt = np.float64 if dtype else np.float32
+    dev = torch.device("cuda:0")
+    info_t = torch.zeros((nfr, code.Kw), dtype=torch.int32, device=dev)
+    llr_t = torch.empty((nfr, N), dtype=torch.float64 if dtype else torch.float32, device=dev)
+    code.gen_frames_dev(info_t.data_ptr(), llr_t.data_ptr(), npdt, n0, 21, 0, nfr, crc=True)
+
+    def search():
+        hat = torch.zeros((nfr, code.Kw), dtype=torch.int32, device=dev)
+        runs = torch.zeros(nfr, dtype=torch.int32, device=dev)
+        ok = torch.zeros(nfr, dtype=torch.uint8, device=dev)
+        last = torch.zeros((nfr, 3), dtype=torch.int32, device=dev)
+        code.pbf_decode_dev(llr_t.data_ptr(), npdt, 3, hat.data_ptr(), nfr, runs_ptr=runs.data_ptr(), ok_ptr=ok.data_ptr(),
+                            last_ptr=last.data_ptr())
+        code.ctx.sync()
+        return hat.cpu().numpy(), runs.cpu().numpy(), ok.cpu().numpy(), last.cpu().numpy(), code.last_launch()["kernel"]
+
+    pieces = search()
+    monkeypatch.setenv("POLAR_PBF_SPLIT", "0")
+    whole = search()
+    assert pieces[4].startswith("pbf_reg_kernel") and pieces[4].endswith("+pairs+triples") and whole[4].startswith("pbf_decode_kernel")
+    for name, a, b in zip(("bits", "runs", "crc", "flips"), pieces[:4], whole[:4]):
+        assert np.array_equal(a, b), (name, np.flatnonzero((a != b).reshape(nfr, -1).any(axis=1))[:5])
+    ok, last = whole[2], whole[3]
+    assert (ok[last[:, 2] >= 0] == 1).any()      # some frames needed all three flips
+    assert ((last[:, 1] >= 0) & (last[:, 2] < 0)).any() and (ok == 0).any()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N,K,poly,T,nfr,snr,dtype", [(32, 20, 0x107, 1, 3000, 1.0, 0), (32, 20, 0x107, 2, 2000, 1.0, 1), (64, 30, 0x107, 2, 2000, 1.0, 0),
                                                        (512, 280, 0x1800063, 1, 3000, 1.5, 1), (512, 280, 0x1800063, 2, 3000, 2.0, 0),
                                                        (1024, 536, 0x1800063, 1, 4000, 1.5, 1)])
