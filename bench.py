@@ -438,7 +438,7 @@ def main():
                                                 "roofline": leg_roofline(li["kernel"], li["last_ms"], nb, 1024, 536, paths=8)}
             # progressive bit flipping on the same frames: fast SC on all, CRC test, flip search on the failures
             cca.set_reliability(pcf.GA(1024, 536, 2.0))
-            for T, nb in ((1, 1 << 20), (2, 1 << 18)):  # a failing frame costs ~10^2 SC runs at T = 1, ~10^4 at T = 2
+            for T, nb in ((1, 1 << 20), (2, 1 << 18), (3, 1 << 15)):  # a failing frame costs ~10^2 SC runs at T = 1, ~10^4 at T = 2, ~10^5 at T = 3 (the level cn/simulator.py:33 sets)
                 rn = torch.zeros(nb, dtype=torch.int32, device=dev)
                 cca.pbf_decode_dev(lca.data_ptr(), np.float32, T, hca.data_ptr(), nb, runs_ptr=rn.data_ptr())
                 ctx.sync()

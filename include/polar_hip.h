@@ -193,7 +193,9 @@ int polar_sc_decode_flip(polar_code *code, const void *llr, int dtype, const int
  * info_hat [B x K]: information word of the last SC run made for the frame, CRC bits included (the reference
  * returns it whether or not its CRC holds); runs [B]: SC runs the reference would have made (1 = no flipping);
  * crc_ok [B]: 1 if the returned word passes the CRC; last_seq [B x 3]: flips of the last run, -1 padded.
- * runs, crc_ok, last_seq may be NULL.  Frames whose first SC run passes the CRC never enter the search. */
+ * runs, crc_ok, last_seq may be NULL.  Frames whose first SC run passes the CRC never enter the search.  With two or three
+ * flips (N <= 1024) the frames that fail every single flip are searched in (frame, first flip) pieces by all wavefronts of the
+ * GPU, so one frame that needs 10^5 runs does not hold the call: same runs, flips, flags and bits as the sequential search. */
 int polar_pbf_decode(polar_code *code, const void *llr, int dtype, int max_level, uint8_t *info_hat, int32_t *runs,
                      uint8_t *crc_ok, int32_t *last_seq, int64_t B, int space);
 int polar_pbf_decode_packed(polar_code *code, const void *llr, int dtype, int max_level, uint32_t *info_hat,
@@ -205,7 +207,7 @@ int polar_pbf_decode_packed(polar_code *code, const void *llr, int dtype, int ma
  * file-scope device array of 4 MiB + 256 B that each GPU the library runs on holds until the process ends.
  * Limits: B <= 2^20 frames per call (more is rejected with POLAR_EINVAL), N <= 1024; polar_code_set_crc and (for
  * max_level >= 1) polar_code_set_reliability must have been called: they build every table the search needs.
- * With max_level = 2 the search runs with one wavefront per failed frame and LDS-staged SC passes (the search in pieces that
+ * With max_level = 2 or 3 the search runs with one wavefront per failed frame and LDS-staged SC passes (the search in pieces that
  * polar_pbf_decode_packed uses needs a workspace the array has no room for): same results, several times slower.
  * The context's timing bracket (polar_ctx_enable_timing) synchronises after each launch, which capture forbids: with it on
  * the call is refused (POLAR_EINVAL).

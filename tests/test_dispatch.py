@@ -60,7 +60,9 @@ CONFIGS = [
     ("PBF one flip", OP_PBF, 1024, 536, F32, 1, OUT_INFO, DQ_CRC, "pbf_reg_kernel"),
     ("PBF two flips in pieces", OP_PBF, 1024, 536, F64, 2, OUT_INFO, DQ_CRC | DQ_SPLIT, "pbf_reg_kernel"),
     ("PBF two flips, no workspace", OP_PBF, 1024, 536, F32, 2, OUT_INFO, DQ_CRC, "pbf_decode_kernel"),
-    ("PBF three flips", OP_PBF, 1024, 536, F32, 3, OUT_INFO, DQ_CRC | DQ_SPLIT, "pbf_decode_kernel"),
+    ("PBF three flips in pieces", OP_PBF, 1024, 536, F32, 3, OUT_INFO, DQ_CRC | DQ_SPLIT, "pbf_reg_kernel"),
+    ("PBF three flips, no workspace", OP_PBF, 1024, 536, F32, 3, OUT_INFO, DQ_CRC, "pbf_decode_kernel"),
+    ("PBF three flips, long code", OP_PBF, 2048, 1048, F32, 3, OUT_INFO, DQ_CRC | DQ_SPLIT, "pbf_decode_kernel"),
     ("scDecoder(sequenceU)", OP_PBF, 1024, 536, F64, 1, OUT_INFO | OUT_UHAT | OUT_DECLLR, DQ_FLIP_LIST, "pbf_decode_kernel"),
 ]
 
