@@ -208,7 +208,9 @@ int polar_pbf_decode_packed(polar_code *code, const void *llr, int dtype, int ma
  * Limits: B <= 2^20 frames per call (more is rejected with POLAR_EINVAL), N <= 1024; polar_code_set_crc and (for
  * max_level >= 1) polar_code_set_reliability must have been called: they build every table the search needs.
  * With max_level = 2 or 3 the search runs with one wavefront per failed frame and LDS-staged SC passes (the search in pieces that
- * polar_pbf_decode_packed uses needs a workspace the array has no room for): same results, several times slower.
+ * polar_pbf_decode_packed uses needs a workspace the array has no room for): same results, several times slower with two
+ * flips; with three, one wavefront makes the up to 10^5 runs of a frame that needs the third level (tens of seconds at
+ * N = 1024 whatever the batch): callers that can allocate should use polar_pbf_decode_packed for three flips.
  * The context's timing bracket (polar_ctx_enable_timing) synchronises after each launch, which capture forbids: with it on
  * the call is refused (POLAR_EINVAL).
  * All calls on one GPU share that array: calls that overlap on one GPU (two streams, two contexts) race. */
