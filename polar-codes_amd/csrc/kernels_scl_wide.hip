@@ -129,6 +129,14 @@ template <int NLOG, int LMAX, typename T> struct WideDec {
     // for C = 64, in W[2..3] for C = 128, in W[4..7] for C = 256; the root (N / 2 bits per lane) fills Rt from bit 0
     static constexpr int SW = NLOG >= 10 ? 8 : 4;
     uint64_t A[SW], Bp[SW], Rt[SW];
+#ifndef POLAR_WIDE_EAGER_A
+#define POLAR_WIDE_EAGER_A 1
+#endif
+    static constexpr bool EAGER_A = POLAR_WIDE_EAGER_A != 0;
+#ifndef POLAR_WIDE_EAGER_L_TOP
+#define POLAR_WIDE_EAGER_L_TOP 1
+#endif
+    static constexpr int EAGER_L_TOP = POLAR_WIDE_EAGER_L_TOP;  // LLR levels up to this one travel with the path (level 1 is x)
     T pm;
     uint32_t oL[2], oP[2];  // owner rows, 5 bits per level: levels 1 .. 6 in word 0, from 7 on in word 1; oL[1] bit 31: see node2
     T x;                    // my element of the enclosing 2-leaf node's LLRs while its first leaf is decided
@@ -161,7 +169,8 @@ template <int NLOG, int LMAX, typename T> struct WideDec {
     }
     template <int L> __device__ __forceinline__ T ld_from(int j, int src) const
     {
-        if constexpr (L >= 7) return memu[(St::mem_off(L) + j) * 64 + src];
+        if constexpr (L <= EAGER_L_TOP) return R[(1 << (L - 1)) + j];  // travels with the path
+        else if constexpr (L >= 7) return memu[(St::mem_off(L) + j) * 64 + src];
         else if constexpr (L == St::LDS_LEVEL) return lds6u[j * 64 + src];
         else return wb_f(R[(1 << (L - 1)) + j], src);
     }
@@ -201,10 +210,14 @@ template <int NLOG, int LMAX, typename T> struct WideDec {
         return b;
     }
     // the C bits of plane-0 level that lanes `src` hold
+    // (the levels of up to 32 bits per lane, all in W[0], travel with the path at a fork or prune -- take_over -- so they are
+    // the lane's own: the narrow levels are walked most often, and a fetch there is a dependent round trip per step)
     template <int C> __device__ __forceinline__ Bits fetch_bits(int src) const
     {
         Bits b{{0, 0, 0, 0}};
-        if constexpr (C <= 16) b.w[0] = (uint64_t)((wb_u((uint32_t)A[0], src) >> C) & ((1u << C) - 1u));
+        if constexpr (C <= 16 && EAGER_A) b.w[0] = (uint64_t)(((uint32_t)A[0] >> C) & ((1u << C) - 1u));
+        else if constexpr (C == 32 && EAGER_A) b.w[0] = A[0] >> 32;
+        else if constexpr (C <= 16) b.w[0] = (uint64_t)((wb_u((uint32_t)A[0], src) >> C) & ((1u << C) - 1u));
         else if constexpr (C == 32) b.w[0] = (uint64_t)wb_u((uint32_t)(A[0] >> 32), src);
         else if constexpr (C == 64) b.w[0] = wb_u64(A[1], src);
         else if constexpr (C == 128) {
@@ -391,6 +404,9 @@ template <int NLOG, int LMAX, typename T> struct WideDec {
         oL[1] = wb_u(oL[1], src);
         oP[0] = wb_u(oP[0], src);
         oP[1] = wb_u(oP[1], src);
+        if constexpr (EAGER_A) A[0] = wb_u64(A[0], src);
+#pragma unroll
+        for (int i = 2; i < (2 << (EAGER_L_TOP - 1)); i++) R[i] = wb_f(R[i], src);
         if (WITH_X) x = wb_f(x, src);
     }
 
