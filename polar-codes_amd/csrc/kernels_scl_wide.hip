@@ -425,7 +425,7 @@ template <int NLOG, int LMAX, typename T> struct WideDec {
             T ae;
             const bool big = sure_exponent(v, ae);
             const T cpm_a = pm + (T)1;
-            const T next = wb_f(cpm_a, lane + 2);  // the agreeing extension of the next list position
+            const T next = next_position(cpm_a);  // the agreeing extension of the next list position
             const T other = pm + ((T)2 - ae);
             const T last = lane_of(cpm_a, 2 * (LMAX - 1));
             // one expression without short-circuit evaluation (nested branches on the lanes' own outcomes are slower)
@@ -514,10 +514,17 @@ template <int NLOG, int LMAX, typename T> struct WideDec {
         if constexpr (sizeof(Key) == 4) return (Key)__builtin_amdgcn_readlane((int)k, src);
         else return ((Key)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k, src);
     }
-    static __device__ __forceinline__ Key key_from(Key k, int src)
+    // the value the next list position (lane + 2) holds: two wavefront shifts by one lane, which stay on the vector ALU (a
+    // ds_bpermute is a round trip through the LDS pipeline in the middle of the leaf's dependent chain); lanes 62 and 63 get
+    // what the shift leaves there and belong to the last position, which has no next
+    template <typename V> static __device__ __forceinline__ V next_position(V v)
     {
-        if constexpr (sizeof(Key) == 4) return wb_u(k, src);
-        else return wb_u64(k, src);
+        return dpp_mov<0x130>(dpp_mov<0x130>(v));  // wave_shl:1 twice
+    }
+    static __device__ __forceinline__ Key next_position_key(Key k)
+    {
+        if constexpr (sizeof(Key) == 4) return dpp_mov_u32<0x130>(dpp_mov_u32<0x130>(k));
+        else return ((Key)dpp_mov_u32<0x130>(dpp_mov_u32<0x130>((uint32_t)(k >> 32))) << 32) | dpp_mov_u32<0x130>(dpp_mov_u32<0x130>((uint32_t)k));
     }
 
     // Ranking by merging, for a common shape of a full list: the agreeing extensions (the candidate of each path that
@@ -535,7 +542,7 @@ template <int NLOG, int LMAX, typename T> struct WideDec {
         const bool keeper = (uint32_t)h == a;              // my candidate is my path's agreeing extension
         const Key okey = swap2_key(key);
         const Key kk = keeper ? key : okey;                // my path's agreeing extension, in both of its lanes
-        const Key kk_next = key_from(kk, lane + 2);
+        const Key kk_next = next_position_key(kk);
         const bool in_order = !alive || p == LMAX - 1 || kk > kk_next;
         const Key bar = key_of_lane(kk, 2 * (LMAX - 1));
         const bool contender = alive && !keeper && key >= bar;
