@@ -19,7 +19,8 @@
 // lexicographic order of (first flip's rank, second flip's rank); here the smallest successful pair wins through a
 // 64-bit atomicMin per frame, pairs that can no longer win are skipped, and pbf_pairs_finish_kernel repeats the one
 // run whose outputs the frame keeps (the winner, or the last run of the search if nothing passed) and derives the
-// run count from the candidate counts, so results do not depend on the order the pairs were worked on.
+// run count from the candidate counts, so results do not depend on the order the pairs were worked on.  Three flips
+// continue the same way on the frames no pair helped (pbf_triples_kernel), where one frame costs up to 10^5 runs.
 #include <stdio.h>
 
 #include <algorithm>
@@ -321,6 +322,7 @@ template <typename T> __global__ void __launch_bounds__(64) pbf_decode_kernel(PB
             if (lane == 0) {
                 p.rows2[slot] = (uint32_t)f;
                 p.best[slot] = ~0ull;
+                if (p.best3) p.best3[slot] = ~0ull;
             }
         }
         wave_sync();
@@ -412,6 +414,144 @@ template <typename T> __global__ void __launch_bounds__(64) pbf_pairs_finish_ker
                 p.last_seq[f * 3] = fl0;
                 p.last_seq[f * 3 + 1] = fl1;
                 p.last_seq[f * 3 + 2] = -1;
+            }
+        }
+        wave_sync();
+    }
+}
+
+// Third level of the split search, on the frames no pair helped.  Work item = (first flip's rank a, frame): the run with the
+// first flip alone ranks the second flips; for each of them in rank order the run with both ranks the third flips, which are
+// tested in rank order.  The reference walks level 3's nodes in the order level 2 appended them (cn/polarCode.py:1596-1626),
+// i.e. the lexicographic order of the three ranks, and stops at the first success; here the smallest successful triple of
+// ranks (20 bits each in a 64-bit word, all ones = none) wins through an atomicMin per frame.
+template <typename T> __global__ void __launch_bounds__(64) pbf_triples_kernel(PBFParams<T> p, const uint32_t *__restrict__ ops)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    PBFWave<T> w(p, ops, smem);
+    const uint64_t n2 = *p.nrows2;
+    const uint64_t items = n2 * (uint64_t)p.nS0;
+    uint16_t *order1 = w.order, *order2 = w.order + p.maxS;
+    for (;;) {
+        const uint64_t wi = w.next_item(p.work);
+        if (wi >= items) break;
+        const uint32_t a = (uint32_t)(wi / n2), slot = (uint32_t)(wi % n2);
+        if (load_best(p.best + slot) != ~0ull) continue;  // a pair passed
+        if ((load_best(p.best3 + slot) >> 40) < a) continue;
+        const int fl0 = p.order_rec[(size_t)slot * p.nS0 + a];
+        const int b0 = p.crit_off[fl0];
+        const int cnt1 = p.crit_off[fl0 + 1] - b0;
+        if (cnt1 == 0 || p.crit_sum[fl0] == 0) continue;
+        w.frame((int64_t)p.rows2[slot]);
+        w.run(fl0, -1, -1, false);
+        w.rank(p.crit_idx + b0, cnt1, order1);
+        bool done = false;
+        for (int b = 0; b < cnt1 && !done; b++) {
+            if ((load_best(p.best3 + slot) >> 20) < (((unsigned long long)a << 20) | (unsigned long long)b)) break;
+            const int fl1 = order1[b];
+            const int c0 = p.crit_off[fl1];
+            const int cnt2 = p.crit_off[fl1 + 1] - c0;
+            if (cnt2 == 0) continue;
+            w.run(fl0, fl1, -1, false);
+            w.rank(p.crit_idx + c0, cnt2, order2);
+            for (int c = 0; c < cnt2; c++) {
+                const unsigned long long here = ((unsigned long long)a << 40) | ((unsigned long long)b << 20) | (unsigned long long)c;
+                if (load_best(p.best3 + slot) < here) {
+                    done = true;
+                    break;
+                }
+                if (w.run(fl0, fl1, (int)order2[c], true)) {
+                    if (w.lane == 0) atomicMin(p.best3 + slot, here);
+                    done = true;
+                    break;
+                }
+            }
+        }
+    }
+}
+
+// Outputs of the frames the pair and triple searches worked on: the winner's run, or - nothing passed - the last tested run
+// of the whole search in the reference's order; the number of tested runs follows from the candidate counts (crit_sum: the
+// candidates two levels below a flip).  One wavefront per frame.
+template <typename T> __global__ void __launch_bounds__(64) pbf_triples_finish_kernel(PBFParams<T> p, const uint32_t *__restrict__ ops)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    PBFWave<T> w(p, ops, smem);
+    const int lane = w.lane;
+    const uint64_t n2 = *p.nrows2;
+    uint16_t *order1 = w.order, *order2 = w.order + p.maxS;
+    auto cnt_of = [&](int fl) { return p.crit_off[fl + 1] - p.crit_off[fl]; };
+    for (uint64_t slot = blockIdx.x; slot < n2; slot += gridDim.x) {
+        const unsigned long long best = p.best[slot], best3 = p.best3[slot];
+        const bool found2 = best != ~0ull, found3 = !found2 && best3 != ~0ull;
+        const uint16_t *rec = p.order_rec + (size_t)slot * p.nS0;
+        const int a2 = (int)(best >> 48), b2 = (int)((best >> 32) & 0xFFFFu);
+        const int a3 = (int)(best3 >> 40), b3 = (int)((best3 >> 20) & 0xFFFFFu), c3 = (int)(best3 & 0xFFFFFu);
+        const int upto2 = found2 ? a2 : p.nS0, upto3 = found2 ? 0 : found3 ? a3 : p.nS0;
+        int before2 = 0, before3 = 0, last2 = -1, last3 = -1;
+        for (int j = lane; j < p.nS0; j += 64) {
+            const int fl = rec[j];
+            const int cnt = cnt_of(fl), below = p.crit_sum[fl];
+            if (j < upto2) before2 += cnt;
+            if (j < upto3) before3 += below;
+            if (cnt > 0) last2 = j;
+            if (below > 0) last3 = j;
+        }
+        for (int off = 1; off < 64; off <<= 1) {
+            before2 += __shfl_xor(before2, off, 64);
+            before3 += __shfl_xor(before3, off, 64);
+            last2 = max(last2, __shfl_xor(last2, off, 64));
+            last3 = max(last3, __shfl_xor(last3, off, 64));
+        }
+        if (!found2 && !found3 && last2 < 0) continue;  // no pair exists (so no triple either): the single-flip level's outputs stand
+        const int64_t f = (int64_t)p.rows2[slot];
+        w.frame(f);
+        int fl0, fl1, fl2 = -1, nruns = 1 + p.nS0 + before2;
+        if (found2) {
+            fl0 = (int)((best >> 16) & 0xFFFFu);
+            fl1 = (int)(best & 0xFFFFu);
+            nruns += b2 + 1;
+        } else if (found3 || last3 >= 0) {
+            fl0 = rec[found3 ? a3 : last3];
+            const int cnt1 = cnt_of(fl0);
+            w.run(fl0, -1, -1, false);
+            w.rank(p.crit_idx + p.crit_off[fl0], cnt1, order1);
+            nruns += before3;
+            int bsel;
+            if (found3) {
+                bsel = b3;
+                int s = 0;
+                for (int j = lane; j < b3; j += 64) s += cnt_of((int)order1[j]);
+                for (int off = 1; off < 64; off <<= 1) s += __shfl_xor(s, off, 64);
+                nruns += s + c3 + 1;
+            } else {
+                bsel = -1;
+                for (int j = lane; j < cnt1; j += 64)
+                    if (cnt_of((int)order1[j]) > 0) bsel = j;
+                for (int off = 1; off < 64; off <<= 1) bsel = max(bsel, __shfl_xor(bsel, off, 64));
+            }
+            fl1 = order1[bsel];
+            const int cnt2 = cnt_of(fl1);
+            w.run(fl0, fl1, -1, false);
+            w.rank(p.crit_idx + p.crit_off[fl1], cnt2, order2);
+            fl2 = order2[found3 ? c3 : cnt2 - 1];
+        } else {
+            // no triple exists: the last pair of level 2 was the last tested run
+            fl0 = rec[last2];
+            const int cnt = cnt_of(fl0);
+            w.run(fl0, -1, -1, false);
+            w.rank(p.crit_idx + p.crit_off[fl0], cnt, order1);
+            fl1 = order1[cnt - 1];
+        }
+        w.run(fl0, fl1, fl2, true);
+        for (int j = lane; j < p.Kw; j += 64) p.info_hat[f * p.Kw + j] = w.iw[j];
+        if (lane == 0) {
+            if (p.runs) p.runs[f] = nruns;
+            if (p.crc_ok) p.crc_ok[f] = (found2 || found3) ? 1 : 0;
+            if (p.last_seq) {
+                p.last_seq[f * 3] = fl0;
+                p.last_seq[f * 3 + 1] = fl1;
+                p.last_seq[f * 3 + 2] = fl2;
             }
         }
         wave_sync();
@@ -510,11 +650,15 @@ static int launch_pbf_t(polar_code *c, const void *llr, const uint32_t *rows, co
     auto kern = pbf_decode_kernel<T>;
     auto kern2 = pbf_pairs_kernel<T>;
     auto kern3 = pbf_pairs_finish_kernel<T>;
+    auto kern4 = pbf_triples_kernel<T>;
+    auto kern5 = pbf_triples_finish_kernel<T>;
     if (lds > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (split) {
             HIP_TRY(hipFuncSetAttribute((const void *)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             HIP_TRY(hipFuncSetAttribute((const void *)kern3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIP_TRY(hipFuncSetAttribute((const void *)kern4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIP_TRY(hipFuncSetAttribute((const void *)kern5, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
     }
     int occ = 0;
@@ -533,12 +677,20 @@ static int launch_pbf_t(polar_code *c, const void *llr, const uint32_t *rows, co
         p.max_level = 2;
         hipLaunchKernelGGL(kern2, dim3((unsigned)(ctx->num_cus * occ2)), dim3(64), lds, ctx->stream, p, ops);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(kern3, dim3((unsigned)std::min<int64_t>(B, (int64_t)ctx->num_cus * occ2)), dim3(64), lds, ctx->stream, p, ops);
+        if (max_level == 3) {
+            p.work = split->ctr + 2;
+            p.max_level = 3;
+            hipLaunchKernelGGL(kern4, dim3((unsigned)(ctx->num_cus * occ2)), dim3(64), lds, ctx->stream, p, ops);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(kern5, dim3((unsigned)std::min<int64_t>(B, (int64_t)ctx->num_cus * occ2)), dim3(64), lds, ctx->stream, p, ops);
+        } else {
+            hipLaunchKernelGGL(kern3, dim3((unsigned)std::min<int64_t>(B, (int64_t)ctx->num_cus * occ2)), dim3(64), lds, ctx->stream, p, ops);
+        }
         HIP_TRY(hipGetLastError());
     }
     float ms = tm.stop();
     snprintf(c->last.kernel, sizeof(c->last.kernel), "pbf_decode_kernel<%s>/T%d%s", sizeof(T) == 4 ? "float" : "double", max_level,
-             split ? "+pairs" : "");
+             !split ? "" : max_level == 3 ? "+pairs+triples" : "+pairs");
     c->last.lanes_per_frame = 64;
     c->last.lds_bytes_per_block = (int)lds;
     c->last.block_threads = 64;
@@ -556,8 +708,8 @@ int launch_pbf(polar_code *c, const void *llr, int dtype, const uint32_t *rows, 
         polar_set_error("flip decoder: N=%d exceeds the supported maximum of 4096", c->N);
         return POLAR_EUNSUPPORTED;
     }
-    if (split && ((max_level != 2 && !(max_level == 3 && split->best3 && pbf_split3_supported(c))) || flips_in || u_hat || dec_llr || !crc)) {
-        polar_set_error("flip decoder: the split search serves two-flip (and, in registers, three-flip) CRC searches without side outputs only");
+    if (split && ((max_level != 2 && !(max_level == 3 && split->best3)) || flips_in || u_hat || dec_llr || !crc)) {
+        polar_set_error("flip decoder: the split search serves two- and three-flip CRC searches without side outputs only");
         return POLAR_EINVAL;
     }
     if (dtype == POLAR_F32)

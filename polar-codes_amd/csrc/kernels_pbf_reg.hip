@@ -577,13 +577,6 @@ bool pbf_reg_supported(const polar_code *c, const uint32_t *rows, const int32_t 
     return row >= 0 && dispatch_table(nullptr)[row].family == KF_PBF_REG;
 }
 
-bool pbf_split3_supported(const polar_code *c)
-{
-    DispatchQuery q{DQ_OP_PBF, c->n, c->K, 0, 3, DQ_OUT_INFO, DQ_CRC | DQ_SPLIT | dq_switch_flags("POLAR_PBF_KERNEL")};
-    const int row = dispatch_select(q);
-    return row >= 0 && dispatch_table(nullptr)[row].family == KF_PBF_REG;
-}
-
 template <typename T> int launch_pbf_reg(polar_code *c, PBFParams<T> &p, int64_t B, const PbfSplit *split, int max_level)
 {
     return launch_pbf_reg_n<T>(c, p, B, split, max_level);

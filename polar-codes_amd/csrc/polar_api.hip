@@ -777,9 +777,9 @@ static int pbf_device(polar_code *c, const void *dl, int dtype, int max_level, u
     const char *sw = polar_switch("POLAR_PBF_SPLIT");
     const bool whole_frames = sw && atoi(sw) == 0;
     // two flips: the second level is worked on in (frame, first flip) pieces, PBF_SPLIT_FRAMES frames at a time; three flips
-    // the same way where the register search serves them (a frame that needs the third level costs 10^5 runs: one wavefront
-    // per frame would hold the whole launch for seconds)
-    const bool split3 = max_level == 3 && pbf_split3_supported(c);
+    // the same way (a frame that needs the third level costs 10^5 runs: one wavefront per frame would hold the whole launch
+    // for seconds)
+    const bool split3 = max_level == 3;
     if ((max_level != 2 && !split3) || whole_frames) return pbf_device_on(c, dl, dtype, max_level, wi, d_runs, d_ok, d_last, nb, rows, ctr);
     const int64_t cap = std::min(nb, PBF_SPLIT_FRAMES);
     const size_t rec = (size_t)std::max(c->nS0, 1) * 2;

@@ -142,8 +142,6 @@ struct PbfSplit {
     uint16_t *order_rec;
     unsigned long long *best3;     // three flips only
 };
-// the three-flip search in pieces exists in the register search only (the dispatch table's row for it)
-bool pbf_split3_supported(const polar_code *c);
 int launch_pbf(polar_code *c, const void *llr, int dtype, const uint32_t *rows, const unsigned long long *nrows_dev,
                unsigned long long *work, const int32_t *flips_in, int max_level, bool crc, uint32_t *info_hat, uint32_t *u_hat,
                void *dec_llr, int32_t *runs, uint8_t *crc_ok, int32_t *last_seq, int64_t B, const PbfSplit *split = nullptr);

@@ -209,11 +209,12 @@ def test_gpu_pbf_two_flips_in_pieces_equals_whole_frame_search(N, K, poly, nfr, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,K,poly,nfr,snr,dtype", [(64, 30, 0x107, 3000, 1.0, 0), (128, 72, 0x107, 1500, 1.5, 1), (256, 140, 0x1621, 300, 1.5, 0),
-                                                     (32, 20, 0x107, 2000, 0.0, 1)])
-def test_gpu_pbf_three_flips_in_pieces_equals_whole_frame_search(N, K, poly, nfr, snr, dtype, monkeypatch):
-    """Three flips: the search worked on in (frame, first flip) pieces by many wavefronts, SC runs in registers, gives the
-    runs, flips, CRC flags and bits of the depth-first search one wavefront makes per frame (which the oracle tests and
+@pytest.mark.parametrize("N,K,poly,nfr,snr,dtype,family", [(64, 30, 0x107, 3000, 1.0, 0, "reg"), (128, 72, 0x107, 1500, 1.5, 1, "reg"),
+                                                            (256, 140, 0x1621, 300, 1.5, 0, "reg"), (32, 20, 0x107, 2000, 0.0, 1, "reg"),
+                                                            (64, 30, 0x107, 3000, 1.0, 1, "lds"), (128, 72, 0x107, 800, 0.5, 0, "lds")])
+def test_gpu_pbf_three_flips_in_pieces_equals_whole_frame_search(N, K, poly, nfr, snr, dtype, family, monkeypatch):
+    """Three flips: the search worked on in (frame, first flip) pieces by many wavefronts (SC runs in registers, or LDS-staged)
+    gives the runs, flips, CRC flags and bits of the depth-first search one wavefront makes per frame (which the oracle tests and
     the reference's vectors pin): frames that pass with one, two and three flips and frames that never pass."""
     import torch
 
@@ -239,10 +240,13 @@ def test_gpu_pbf_three_flips_in_pieces_equals_whole_frame_search(N, K, poly, nfr
         code.ctx.sync()
         return hat.cpu().numpy(), runs.cpu().numpy(), ok.cpu().numpy(), last.cpu().numpy(), code.last_launch()["kernel"]
 
+    if family == "lds":  # the LDS-staged search (what codes longer than 1024 get) has its own kernels for the pieces
+        monkeypatch.setenv("POLAR_PBF_KERNEL", "lds")
     pieces = search()
     monkeypatch.setenv("POLAR_PBF_SPLIT", "0")
     whole = search()
-    assert pieces[4].startswith("pbf_reg_kernel") and pieces[4].endswith("+pairs+triples") and whole[4].startswith("pbf_decode_kernel")
+    assert pieces[4].startswith("pbf_reg_kernel" if family == "reg" else "pbf_decode_kernel") and pieces[4].endswith("+pairs+triples")
+    assert whole[4].startswith("pbf_decode_kernel") and not whole[4].endswith("triples")
     for name, a, b in zip(("bits", "runs", "crc", "flips"), pieces[:4], whole[:4]):
         assert np.array_equal(a, b), (name, np.flatnonzero((a != b).reshape(nfr, -1).any(axis=1))[:5])
     ok, last = whole[2], whole[3]
