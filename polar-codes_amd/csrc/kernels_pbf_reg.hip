@@ -1,4 +1,4 @@
-// The bit-flipping search with its SC runs in registers (N = 32 .. 1024, fp32 or fp64, one or two flips).
+// The bit-flipping search with its SC runs in registers (N = 32 .. 1024, fp32 or fp64, one to three flips).
 //
 // A run is the every-leaf walk of sc_reg_full_kernel -- sixteen lanes per run, element k of a tree level in lane
 // k mod 16 -- with the flip hook of scDecoder(sequenceU) (cn/polarCode.py:1555-1558) in the 16-leaf nodes.  The four
@@ -9,9 +9,10 @@
 // and with two flips the run with the first flip alone) are the same in all four rows; row 0 leaves its decision LLRs
 // in LDS for the ranking.
 //
-// Three kernels share the code: the single-flip level on the frames that failed their CRC (and the hand-over of
-// frames that fail it entirely to the pair search), the pair search over (first flip's rank, frame) work items, and
-// the pass that writes the outputs of the frames the pair search worked on.  Bookkeeping, work distribution and
+// Five kernels share the code: the single-flip level on the frames that failed their CRC (and the hand-over of
+// frames that fail it entirely to the pair search), the pair search over (first flip's rank, frame) work items, the
+// pass that writes the outputs of the frames the pair search worked on, and for three flips the triple search over
+// the same work items on the frames no pair helped, with its own output pass.  Bookkeeping, work distribution and
 // results are those of kernels_pbf.hip, which keeps the cases this file does not cover.
 #include <stdio.h>
 #include <stdlib.h>
