@@ -1,5 +1,5 @@
-// Register-resident list decoder for long lists: up to L = 32 paths (L = 16 leaves half of the positions empty),
-// N = 64 .. 1024, fp32 or fp64, information bits of the best path (or of the first path in metric order that passes the
+// Register-resident list decoder for long lists: up to L = 32 paths (L = 16 leaves half of the positions empty; at N = 2048
+// also L = 8), N = 64 .. 2048, fp32 or fp64, information bits of the best path (or of the first path in metric order that passes the
 // CRC / equals the transmitted word) and, when asked for, the whole list in metric order with its metrics: one wavefront
 // per frame, two lanes per path.
 //
@@ -10,7 +10,8 @@
 // channel is stored nowhere: it is one f or g away from the channel LLRs, which every path reads and which are staged
 // once per frame in LDS, split by parity, so the two steps that consume it recompute their operands from there (with
 // the path's own partial sums of the root's left half, for the right half); the levels between (N = 512: level 7,
-// 16 KB per wavefront; N = 1024: levels 7 and 8, 48 KB) live lane-major in a slab of global memory per wavefront.
+// 16 KB per wavefront; N = 1024: levels 7 and 8, 48 KB; N = 2048: levels 7 to 9, 112 KB) live lane-major in a slab of global
+// memory per wavefront.
 // Partial sums are bit slices in registers.
 //
 // Forking never copies a slice: as in the 8-lanes-per-path kernel (kernels_scl_reg.hip) every path keeps rows of
@@ -126,8 +127,10 @@ template <int NLOG, int LMAX, typename T> struct WideDec {
     const T *chs;          // the frame's channel LLRs in LDS, [parity][N/2], + my parity's half
     int lane, p, h;
     // partial sums per plane: a level whose nodes have C bits per lane sits in W[0] at bit offset C for C <= 32, in W[1]
-    // for C = 64, in W[2..3] for C = 128, in W[4..7] for C = 256; the root (N / 2 bits per lane) fills Rt from bit 0
-    static constexpr int SW = NLOG >= 10 ? 8 : 4;
+    // for C = 64, in W[C / 64 .. C / 32) from there on (W[2..3] for C = 128, W[4..7] for 256, W[8..15] for 512); the root
+    // (N / 2 bits per lane) fills Rt from bit 0
+    static constexpr int SW = NLOG >= 10 ? N / 128 : 4;
+    static constexpr int BW = SW >= 8 ? SW / 2 : 4;  // words of the widest child
     uint64_t A[SW], Bp[SW], Rt[SW];
 #ifndef POLAR_WIDE_EAGER_A
 #define POLAR_WIDE_EAGER_A 1
@@ -193,19 +196,16 @@ template <int NLOG, int LMAX, typename T> struct WideDec {
 
     // ---- bit slices -----------------------------------------------------------------------------------------
     struct Bits {
-        uint64_t w[4];
+        uint64_t w[BW];
     };
     template <int C> static __device__ __forceinline__ Bits get_bits(const uint64_t *W)
     {
-        Bits b{{0, 0, 0, 0}};
+        Bits b{};
         if constexpr (C <= 32) b.w[0] = (W[0] >> C) & ((((uint64_t)1) << C) - 1);
         else if constexpr (C == 64) b.w[0] = W[1];
-        else if constexpr (C == 128) {
-            b.w[0] = W[2];
-            b.w[1] = W[3];
-        } else {
+        else {
 #pragma unroll
-            for (int i = 0; i < 4; i++) b.w[i] = W[4 + i];
+            for (int i = 0; i < C / 64; i++) b.w[i] = W[C / 64 + i];
         }
         return b;
     }
@@ -214,18 +214,15 @@ template <int NLOG, int LMAX, typename T> struct WideDec {
     // the lane's own: the narrow levels are walked most often, and a fetch there is a dependent round trip per step)
     template <int C> __device__ __forceinline__ Bits fetch_bits(int src) const
     {
-        Bits b{{0, 0, 0, 0}};
+        Bits b{};
         if constexpr (C <= 16 && EAGER_A) b.w[0] = (uint64_t)(((uint32_t)A[0] >> C) & ((1u << C) - 1u));
         else if constexpr (C == 32 && EAGER_A) b.w[0] = A[0] >> 32;
         else if constexpr (C <= 16) b.w[0] = (uint64_t)((wb_u((uint32_t)A[0], src) >> C) & ((1u << C) - 1u));
         else if constexpr (C == 32) b.w[0] = (uint64_t)wb_u((uint32_t)(A[0] >> 32), src);
         else if constexpr (C == 64) b.w[0] = wb_u64(A[1], src);
-        else if constexpr (C == 128) {
-            b.w[0] = wb_u64(A[2], src);
-            b.w[1] = wb_u64(A[3], src);
-        } else {
+        else {
 #pragma unroll
-            for (int i = 0; i < 4; i++) b.w[i] = wb_u64(A[4 + i], src);
+            for (int i = 0; i < C / 64; i++) b.w[i] = wb_u64(A[C / 64 + i], src);
         }
         return b;
     }
@@ -243,20 +240,13 @@ template <int NLOG, int LMAX, typename T> struct WideDec {
             const uint64_t x = (xl.w[0] ^ xr.w[0]) | (xr.w[0] << 32);
             if (root) W[0] = x;
             else W[1] = x;
-        } else if constexpr (C == 64) {
-            W[root ? 0 : 2] = xl.w[0] ^ xr.w[0];
-            W[root ? 1 : 3] = xr.w[0];
-        } else if constexpr (C == 128) {  // the root of N = 512, or the two level-9 nodes of N = 1024
-            const int o = root ? 0 : 4;
-            W[o] = xl.w[0] ^ xr.w[0];
-            W[o + 1] = xl.w[1] ^ xr.w[1];
-            W[o + 2] = xr.w[0];
-            W[o + 3] = xr.w[1];
-        } else {  // 256 bits per child: the root of N = 1024
+        } else {  // whole words: the node's 2 C bits at W[2 C / 64 ..), or from W[0] for the root
+            constexpr int nw = C / 64;
+            const int o = root ? 0 : 2 * nw;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                W[i] = xl.w[i] ^ xr.w[i];
-                W[4 + i] = xr.w[i];
+            for (int i = 0; i < nw; i++) {
+                W[o + i] = xl.w[i] ^ xr.w[i];
+                W[o + nw + i] = xr.w[i];
             }
         }
     }
@@ -283,7 +273,7 @@ template <int NLOG, int LMAX, typename T> struct WideDec {
         constexpr int BMAX = sizeof(T) == 4 ? 16 : 8;  // pairs in flight: 32 registers of operands either way
         constexpr int BT = !MEM ? 1 : c < BMAX ? c : BMAX;
         const int lq = opaque(lane);
-        Bits tb{{0, 0, 0, 0}};
+        Bits tb{};
         if constexpr (FROM_TOP)
             if (right) tb = fetch_bits<(1 << (NLOG - 2))>((int)own_get<St::TOP>(oP) * 2 + h);
 #pragma unroll
@@ -336,7 +326,7 @@ template <int NLOG, int LMAX, typename T> struct WideDec {
         const int srcP = (int)own_get<LEV - 1>(oP) * 2 + h;
         const int srcL = opaque((LEV == NLOG || FROM_TOP) ? 0 : (int)own_get<(LEV == NLOG ? 1 : LEV)>(oL) * 2 + h);
         const Bits bits = fetch_bits<c>(srcP);
-        Bits tb{{0, 0, 0, 0}};
+        Bits tb{};
         if constexpr (FROM_TOP)
             if (right) tb = fetch_bits<(1 << (NLOG - 2))>((int)own_get<St::TOP>(oP) * 2 + h);
 #pragma unroll
@@ -632,7 +622,7 @@ __device__ __forceinline__ uint32_t spread16(uint32_t v)
 // List outputs (pm_out, u_hat_all; either may be NULL) are those of scl_decode_kernel: row f * LMAX + r holds the path of
 // rank r in the stable descending order of the metrics, rows of empty positions keep their index, -inf and zeros.
 template <int NLOG, int LMAX, typename T>
-__global__ void __launch_bounds__(64, sizeof(T) == 4 ? 3 : 2)
+__global__ void __launch_bounds__(64, sizeof(T) == 4 ? (NLOG >= 11 ? 2 : 3) : (NLOG >= 11 ? 1 : 2))
 scl_wide_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, const uint32_t *__restrict__ Apos,
                 uint32_t *__restrict__ info_hat, int64_t B, int K, int Kw, T *__restrict__ slab, const uint32_t *__restrict__ crcS,
                 const uint32_t *__restrict__ truth, double *__restrict__ pm_out, uint32_t *__restrict__ u_hat_all)
@@ -652,7 +642,7 @@ scl_wide_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, c
     d.memu = slab + (size_t)blockIdx.x * (WideStore<NLOG, T>::MEM_ROWS > 0 ? WideStore<NLOG, T>::MEM_ROWS : 1) * 64;
     d.chs = chan_s + d.h * (N / 2);
     d.lds6u = lvl6_s;
-    const uint32_t maskv = maskw[(d.lane & 31) < NW ? (d.lane & 31) : 0];
+    const uint32_t maskv = NW > 32 ? maskw[d.lane < NW ? d.lane : 0] : maskw[(d.lane & 31) < NW ? (d.lane & 31) : 0];
 
     for (int64_t f = blockIdx.x; f < B; f += gridDim.x) {
         // channel LLRs of the frame: coalesced 16-byte loads, stored split by parity (element 2j + h at [h][j])
@@ -698,8 +688,8 @@ scl_wide_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, c
         if (act && d.h == 0) inv[rank] = (uint32_t)d.p;  // active paths take the ranks 0 .. Lcur-1
         wave_sync();
         constexpr int STREAM = 2 * Dec::SW;                   // words per lane stream
-        uint32_t *bw = reinterpret_cast<uint32_t *>(chan_s);  // [2][STREAM] lane streams, then NW words of x_hat / u_hat at +32
-        uint32_t *uw = bw + 32;
+        uint32_t *bw = reinterpret_cast<uint32_t *>(chan_s);  // [2][STREAM] lane streams, then NW words of x_hat / u_hat
+        uint32_t *uw = bw + (2 * STREAM > 32 ? 2 * STREAM : 32);
         // u_hat of the path in list position pos, as natural-order words in LDS: its root partial sums (x_hat, lane h holds
         // elements 2j + h), then x_hat F^{(x)n}
         auto path_words = [&](int pos) {
@@ -807,6 +797,12 @@ template <int NLOG>
 int launch_wide_l(polar_code *c, const void *llr, int dtype, uint32_t *info_hat, double *pm, uint32_t *u_hat_all, int64_t B, int L, bool crc,
                   const uint32_t *truth)
 {
+    if constexpr (NLOG == 11) {  // N = 2048, beyond the eight-lanes-per-path kernel: lists of 8 run here with a quarter of the lanes
+        if (L == 8) {
+            if (dtype == POLAR_F32) return launch_wide_t<NLOG, 8, float>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
+            return launch_wide_t<NLOG, 8, double>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
+        }
+    }
     if (dtype == POLAR_F32) {
         if (L == 32) return launch_wide_t<NLOG, 32, float>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
         return launch_wide_t<NLOG, 16, float>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
@@ -839,7 +835,16 @@ int launch_scl_wide(polar_code *c, const void *llr, int dtype, uint32_t *info_ha
 {
     if (B == 0) return POLAR_OK;
     switch (c->n) {
-#ifdef POLAR_WIDE_DEV_ONE  // development builds: the (512, L = 32) kernels only, seconds to compile
+#ifdef POLAR_WIDE_DEV_LONG  // development builds: the (2048, L = 32) kernels only
+    case 11:
+        if (L == 32 && dtype == POLAR_F32) return launch_wide_t<11, 32, float>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
+        if (L == 32) return launch_wide_t<11, 32, double>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
+        if (L == 16 && dtype == POLAR_F32) return launch_wide_t<11, 16, float>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
+        if (L == 8 && dtype == POLAR_F32) return launch_wide_t<11, 8, float>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
+        if (L == 8) return launch_wide_t<11, 8, double>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
+        polar_set_error("development build: L = 32 only");
+        return POLAR_EUNSUPPORTED;
+#elif defined(POLAR_WIDE_DEV_ONE)  // development builds: the (512, L = 32) kernels only, seconds to compile
     case 9:
         if (L == 32 && dtype == POLAR_F32) return launch_wide_t<9, 32, float>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
         if (L == 32) return launch_wide_t<9, 32, double>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
@@ -851,6 +856,7 @@ int launch_scl_wide(polar_code *c, const void *llr, int dtype, uint32_t *info_ha
     case 8: return launch_wide_l<8>(c, llr, dtype, info_hat, pm, u_hat_all, B, L, crc, truth);
     case 9: return launch_wide_l<9>(c, llr, dtype, info_hat, pm, u_hat_all, B, L, crc, truth);
     case 10: return launch_wide_l<10>(c, llr, dtype, info_hat, pm, u_hat_all, B, L, crc, truth);
+    case 11: return launch_wide_l<11>(c, llr, dtype, info_hat, pm, u_hat_all, B, L, crc, truth);
 #endif
     default: polar_set_error("wide list kernel: unsupported length"); return POLAR_EUNSUPPORTED;
     }

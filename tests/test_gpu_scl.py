@@ -332,3 +332,57 @@ def test_scl_fp64_wide_kernel_equals_lds_kernel(monkeypatch, cons, N, K, L):
     assert np.array_equal(a2, b)
     assert np.array_equal(auh, buh), np.flatnonzero(np.any(auh != buh, axis=(1, 2)))[:20]
     assert np.array_equal(apm, bpm), np.flatnonzero(np.any(apm != bpm, axis=1))[:20]
+
+
+@pytest.mark.parametrize("L,dtype", [(8, np.float32), (16, np.float32), (8, np.float64), (16, np.float64)])
+def test_scl_wide_kernel_at_2048_equals_lds_kernel(monkeypatch, L, dtype):
+    """N = 2048, beyond the eight-lanes-per-path kernel: lists of 8 and 16 on the two-lanes-per-path kernel against the
+    LDS-staged kernel (same operations in the same order): identical bits in fp32, identical bits, survivors and metrics in
+    fp64, frames with exactly tied metrics and with overflowing metrics included."""
+    N, K = 2048, 1024
+    mask = pcf.degaBuild(N, K, 2.0)
+    code = _native.Code(_native.default_ctx(), mask)
+    rs = np.random.RandomState(N + L)
+    B = 401 if dtype is np.float32 else 151
+    x = oracle.polar_encode(rs.randint(0, 2, size=(B, K)), mask).reshape(B, N)
+    n0 = 1.0 / (K / N * 10 ** (1.0 / 10))
+    llr = code.channel_llr(x, n0, 23, 0, dtype)
+    llr[:30] = np.round(llr[:30])
+    llr[30:33] *= 200.0
+    lists = dtype is np.float64
+    monkeypatch.delenv("POLAR_SCL_KERNEL", raising=False)
+    a, apm, auh = code.scl_decode(llr, L, want_list=lists)
+    assert code.last_launch()["kernel"].startswith("scl_wide_kernel<11"), code.last_launch()
+    monkeypatch.setenv("POLAR_SCL_KERNEL", "lds")
+    b, bpm, buh = code.scl_decode(llr, L, want_list=lists)
+    assert code.last_launch()["kernel"].startswith("scl_decode_kernel")
+    assert np.array_equal(a, b), np.flatnonzero(np.any(a != b, axis=1))[:20]
+    if lists:
+        assert np.array_equal(auh, buh), np.flatnonzero(np.any(auh != buh, axis=(1, 2)))[:20]
+        assert np.array_equal(apm, bpm), np.flatnonzero(np.any(apm != bpm, axis=1))[:20]
+
+
+def test_scl_wide_kernel_at_2048_with_32_paths_vs_oracle():
+    """N = 2048 with 32 paths, which the LDS-staged kernel has no room for: fp64 against the CPU oracle (the reference's
+    arithmetic): decoded bits, the whole sorted list and its metrics, frame by frame; fp32 decodes the same information bits
+    on these frames."""
+    N, K, L = 2048, 1024, 32
+    mask = pcf.degaBuild(N, K, 2.0)
+    code = _native.Code(_native.default_ctx(), mask)
+    rs = np.random.RandomState(7)
+    B = 10
+    x = oracle.polar_encode(rs.randint(0, 2, size=(B, K)), mask).reshape(B, N)
+    n0 = 1.0 / (K / N * 10 ** (1.5 / 10))
+    llr = code.channel_llr(x, n0, 29, 0, np.float64)
+    info, pm, uh = code.scl_decode(llr, L, want_list=True)
+    assert code.last_launch()["kernel"].startswith("scl_wide_kernel<11,double>/L32"), code.last_launch()
+    info32, _, _ = code.scl_decode(llr.astype(np.float32), L)
+    assert code.last_launch()["kernel"].startswith("scl_wide_kernel<11>/L32"), code.last_launch()
+    for f in range(B):
+        ouh, opm, _ = oracle.scl_decode(llr[f], mask, L)
+        assert np.array_equal(uh[f][:len(ouh)], ouh), f
+        # the oracle takes exp2 / log2 from the host's libm, the GPU from its device library: after 1024 information leaves a
+        # last-bit difference in one of them is allowed (the shorter codes' tests compare the GPU kernels with each other bit by bit)
+        np.testing.assert_allclose(pm[f][:len(opm)], opm, rtol=1e-13)
+        assert np.array_equal(info[f], ouh[0][np.asarray(mask) == 1]), f
+    assert np.array_equal(info32, info)
