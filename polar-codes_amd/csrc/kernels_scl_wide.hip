@@ -1,5 +1,5 @@
 // Register-resident list decoder for long lists: up to L = 32 paths (L = 16 leaves half of the positions empty; at N = 2048
-// also L = 8), N = 64 .. 2048, fp32 or fp64, information bits of the best path (or of the first path in metric order that passes the
+// and 4096 also L = 8), N = 64 .. 4096, fp32 or fp64, information bits of the best path (or of the first path in metric order that passes the
 // CRC / equals the transmitted word) and, when asked for, the whole list in metric order with its metrics: one wavefront
 // per frame, two lanes per path.
 //
@@ -10,7 +10,7 @@
 // channel is stored nowhere: it is one f or g away from the channel LLRs, which every path reads and which are staged
 // once per frame in LDS, split by parity, so the two steps that consume it recompute their operands from there (with
 // the path's own partial sums of the root's left half, for the right half); the levels between (N = 512: level 7,
-// 16 KB per wavefront; N = 1024: levels 7 and 8, 48 KB; N = 2048: levels 7 to 9, 112 KB) live lane-major in a slab of global
+// 16 KB per wavefront; N = 1024: levels 7 and 8, 48 KB; N = 2048: levels 7 to 9, 112 KB; N = 4096: 7 to 10, 240 KB) live lane-major in a slab of global
 // memory per wavefront.
 // Partial sums are bit slices in registers.
 //
@@ -584,7 +584,7 @@ template <int NLOG, int LMAX, typename T> struct WideDec {
 };
 
 template <int LEV, int NLOG, int LMAX, typename T>
-__device__ __forceinline__ void wide_node(WideDec<NLOG, LMAX, T> &d, uint32_t maskv, uint32_t idx, int plane, typename KeyOf<T>::type *keys,
+__device__ __forceinline__ void wide_node(WideDec<NLOG, LMAX, T> &d, uint64_t maskv, uint32_t idx, int plane, typename KeyOf<T>::type *keys,
                                           uint32_t *inv)
 {
 #pragma nounroll
@@ -593,7 +593,13 @@ __device__ __forceinline__ void wide_node(WideDec<NLOG, LMAX, T> &d, uint32_t ma
         else d.template step_g<LEV>();
         const uint32_t cidx = 2 * idx + hh;
         if constexpr (LEV == 2) {
-            const uint32_t mw = (uint32_t)__builtin_amdgcn_readlane((int)maskv, (int)(cidx >> 4));
+            // rate-profile word cidx >> 4 (32 positions): lane w holds word w in the low half of maskv and, for N = 4096,
+            // word 64 + w in the high half
+            uint32_t mw = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)maskv, (int)((cidx >> 4) & 63u));
+            if constexpr (NLOG >= 12) {
+                const uint32_t mh = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(maskv >> 32), (int)((cidx >> 4) & 63u));
+                mw = (cidx >> 4) >= 64u ? mh : mw;
+            }
             const uint32_t m2 = (mw >> (2 * (cidx & 15))) & 3u;
             const uint32_t xb = d.node2(d.R[1], m2, keys, inv);
             if (hh) {
@@ -622,7 +628,7 @@ __device__ __forceinline__ uint32_t spread16(uint32_t v)
 // List outputs (pm_out, u_hat_all; either may be NULL) are those of scl_decode_kernel: row f * LMAX + r holds the path of
 // rank r in the stable descending order of the metrics, rows of empty positions keep their index, -inf and zeros.
 template <int NLOG, int LMAX, typename T>
-__global__ void __launch_bounds__(64, sizeof(T) == 4 ? (NLOG >= 11 ? 2 : 3) : (NLOG >= 11 ? 1 : 2))
+__global__ void __launch_bounds__(64, sizeof(T) == 4 ? (NLOG >= 12 ? 1 : NLOG == 11 ? 2 : 3) : (NLOG >= 11 ? 1 : 2))
 scl_wide_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, const uint32_t *__restrict__ Apos,
                 uint32_t *__restrict__ info_hat, int64_t B, int K, int Kw, T *__restrict__ slab, const uint32_t *__restrict__ crcS,
                 const uint32_t *__restrict__ truth, double *__restrict__ pm_out, uint32_t *__restrict__ u_hat_all)
@@ -642,7 +648,8 @@ scl_wide_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, c
     d.memu = slab + (size_t)blockIdx.x * (WideStore<NLOG, T>::MEM_ROWS > 0 ? WideStore<NLOG, T>::MEM_ROWS : 1) * 64;
     d.chs = chan_s + d.h * (N / 2);
     d.lds6u = lvl6_s;
-    const uint32_t maskv = NW > 32 ? maskw[d.lane < NW ? d.lane : 0] : maskw[(d.lane & 31) < NW ? (d.lane & 31) : 0];
+    uint64_t maskv = NW > 32 ? maskw[d.lane < NW ? d.lane : 0] : maskw[(d.lane & 31) < NW ? (d.lane & 31) : 0];
+    if constexpr (NW > 64) maskv |= (uint64_t)maskw[64 + d.lane] << 32;
 
     for (int64_t f = blockIdx.x; f < B; f += gridDim.x) {
         // channel LLRs of the frame: coalesced 16-byte loads, stored split by parity (element 2j + h at [h][j])
@@ -702,15 +709,15 @@ scl_wide_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, c
                 }
             }
             wave_sync();
-            if (d.lane < NW) {
-                const int w = d.lane;
+            for (int w = d.lane; w < NW; w += 64) {
                 const uint32_t s0 = (bw[w >> 1] >> (16 * (w & 1))) & 0xFFFFu, s1 = (bw[STREAM + (w >> 1)] >> (16 * (w & 1))) & 0xFFFFu;
                 uw[w] = butterfly_word(spread16(s0) | (spread16(s1) << 1), NLOG);
             }
             for (int s = 5; s < NLOG; s++) {
                 wave_sync();
                 const int dd = 1 << (s - 5);
-                if (d.lane < NW && !(d.lane & dd)) uw[d.lane] ^= uw[d.lane + dd];
+                for (int w = d.lane; w < NW; w += 64)
+                    if (!(w & dd)) uw[w] ^= uw[w + dd];
             }
             wave_sync();
         };
@@ -725,9 +732,9 @@ scl_wide_kernel(const T *__restrict__ llr, const uint32_t *__restrict__ maskw, c
                 uint32_t *row = u_hat_all + ((size_t)f * LMAX + r) * NW;
                 if (r < d.Lcur) {
                     path_words((int)inv[r]);
-                    if (d.lane < NW) row[d.lane] = uw[d.lane];
-                } else if (d.lane < NW) {
-                    row[d.lane] = 0u;
+                    for (int w = d.lane; w < NW; w += 64) row[w] = uw[w];
+                } else {
+                    for (int w = d.lane; w < NW; w += 64) row[w] = 0u;
                 }
             }
         }
@@ -797,7 +804,7 @@ template <int NLOG>
 int launch_wide_l(polar_code *c, const void *llr, int dtype, uint32_t *info_hat, double *pm, uint32_t *u_hat_all, int64_t B, int L, bool crc,
                   const uint32_t *truth)
 {
-    if constexpr (NLOG == 11) {  // N = 2048, beyond the eight-lanes-per-path kernel: lists of 8 run here with a quarter of the lanes
+    if constexpr (NLOG >= 11) {  // beyond the eight-lanes-per-path kernel: lists of 8 run here with a quarter of the lanes
         if (L == 8) {
             if (dtype == POLAR_F32) return launch_wide_t<NLOG, 8, float>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
             return launch_wide_t<NLOG, 8, double>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
@@ -835,14 +842,12 @@ int launch_scl_wide(polar_code *c, const void *llr, int dtype, uint32_t *info_ha
 {
     if (B == 0) return POLAR_OK;
     switch (c->n) {
-#ifdef POLAR_WIDE_DEV_LONG  // development builds: the (2048, L = 32) kernels only
-    case 11:
-        if (L == 32 && dtype == POLAR_F32) return launch_wide_t<11, 32, float>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
-        if (L == 32) return launch_wide_t<11, 32, double>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
-        if (L == 16 && dtype == POLAR_F32) return launch_wide_t<11, 16, float>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
-        if (L == 8 && dtype == POLAR_F32) return launch_wide_t<11, 8, float>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
-        if (L == 8) return launch_wide_t<11, 8, double>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
-        polar_set_error("development build: L = 32 only");
+#ifdef POLAR_WIDE_DEV_LONG  // development builds: a few of the N = 4096 kernels only
+    case 12:
+        if (L == 32 && dtype == POLAR_F32) return launch_wide_t<12, 32, float>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
+        if (L == 32) return launch_wide_t<12, 32, double>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
+        if (L == 8 && dtype == POLAR_F32) return launch_wide_t<12, 8, float>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
+        polar_set_error("development build: not compiled");
         return POLAR_EUNSUPPORTED;
 #elif defined(POLAR_WIDE_DEV_ONE)  // development builds: the (512, L = 32) kernels only, seconds to compile
     case 9:
@@ -857,6 +862,7 @@ int launch_scl_wide(polar_code *c, const void *llr, int dtype, uint32_t *info_ha
     case 9: return launch_wide_l<9>(c, llr, dtype, info_hat, pm, u_hat_all, B, L, crc, truth);
     case 10: return launch_wide_l<10>(c, llr, dtype, info_hat, pm, u_hat_all, B, L, crc, truth);
     case 11: return launch_wide_l<11>(c, llr, dtype, info_hat, pm, u_hat_all, B, L, crc, truth);
+    case 12: return launch_wide_l<12>(c, llr, dtype, info_hat, pm, u_hat_all, B, L, crc, truth);
 #endif
     default: polar_set_error("wide list kernel: unsupported length"); return POLAR_EUNSUPPORTED;
     }

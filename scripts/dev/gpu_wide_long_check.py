@@ -1,4 +1,4 @@
-# the two-lanes-per-path list decoder at N = 2048: L = 16 against the LDS-staged kernel, L = 32 (which the LDS-staged kernel has
+# the two-lanes-per-path list decoder at N = 2048 (or argv[1] = 4096, where only L = 8 has an LDS-staged counterpart): L = 16 against the LDS-staged kernel, L = 32 (which the LDS-staged kernel has
 # no room for) against the CPU oracle on a few frames; rates
 import sys, os, time; sys.path[:0]=['polar-codes_amd','.']
 os.environ['POLAR_EXPERIMENT']='1'
@@ -6,7 +6,7 @@ import numpy as np, torch, _native, functions as pcf
 from channel import Channel
 from oracle import oracle
 ctx=_native.default_ctx(0); ctx.enable_timing(True)
-N,K=2048,1024
+N=int(sys.argv[1]) if len(sys.argv)>1 else 2048; K=N//2
 mask=pcf.degaBuild(N,K,2.0)
 code=_native.Code(ctx,mask); n0=Channel('BPSK',2.0,'SNRb',K/N).noisePower
 for L,dt,tdt,nb in [(8,np.float32,torch.float32,1<<14),(8,np.float64,torch.float64,1<<13),(16,np.float32,torch.float32,1<<14),(32,np.float32,torch.float32,1<<14),(32,np.float64,torch.float64,1<<13)]:
@@ -18,7 +18,7 @@ for L,dt,tdt,nb in [(8,np.float32,torch.float32,1<<14),(8,np.float64,torch.float
     k=code.last_launch()['kernel']; ctx.sync()
     fe=int((hat!=info).any(dim=1).sum())
     msg='%d %d L %d %s %s %.3f M frames/s fer %.3g'%(N,K,L,dt.__name__,k,nb/(min(ms)*1e-3)/1e6,fe/nb)
-    if L<=16:
+    if L<=16 and not (N==4096 and L==16):
         os.environ['POLAR_SCL_KERNEL']='lds'; nchk=1<<11
         ref=torch.zeros((nchk,code.Kw),dtype=torch.int32,device='cuda'); code.scl_decode_dev(llr.data_ptr(),dt,L,ref.data_ptr(),nchk); k2=code.last_launch()['kernel']; ctx.sync()
         del os.environ['POLAR_SCL_KERNEL']

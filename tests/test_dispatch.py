@@ -56,11 +56,12 @@ CONFIGS = [
     ("C5 fp32 fast", OP_SC, 16384, 8192, F32, 0, OUT_INFO, DQ_FAST, "sc_big_kernel"),
     ("C5 fp32 every leaf", OP_SC, 16384, 8192, F32, 0, OUT_INFO, 0, "sc_decode_kernel<float"),
     ("C5 fp64", OP_SC, 16384, 8192, F64, 0, OUT_INFO | OUT_DECLLR, 0, "sc_decode_kernel<double"),
-    # N = 2048: lists of 8 and more on the two-lanes-per-path kernel, shorter lists LDS-staged
+    # N = 2048, 4096: lists of 8 and more on the two-lanes-per-path kernel, shorter lists LDS-staged
     ("SCL-8 at 2048", OP_SCL, 2048, 1024, F32, 8, OUT_INFO, 0, "scl_wide_kernel"),
     ("SCL-32 at 2048, fp64 lists", OP_SCL, 2048, 1024, F64, 32, OUT_INFO | OUT_UHAT | OUT_PM, 0, "scl_wide_kernel"),
     ("SCL-4 at 2048", OP_SCL, 2048, 1024, F32, 4, OUT_INFO, 0, "scl_decode_kernel"),
-    ("SCL-8 at 4096", OP_SCL, 4096, 2048, F32, 8, OUT_INFO, 0, "scl_decode_kernel"),
+    ("SCL-8 at 4096", OP_SCL, 4096, 2048, F32, 8, OUT_INFO, 0, "scl_wide_kernel"),
+    ("SCL-4 at 4096", OP_SCL, 4096, 2048, F64, 4, OUT_INFO, 0, "scl_decode_kernel"),
     # flip search on the configuration cn/simulator.py sets (512 message bits + CRC-24)
     ("PBF one flip", OP_PBF, 1024, 536, F32, 1, OUT_INFO, DQ_CRC, "pbf_reg_kernel"),
     ("PBF two flips in pieces", OP_PBF, 1024, 536, F64, 2, OUT_INFO, DQ_CRC | DQ_SPLIT, "pbf_reg_kernel"),
@@ -100,9 +101,10 @@ def test_edges_of_the_register_kernels():
     assert kernel(OP_SCL, 64, 4, F64, 32, OUT_INFO, 0).startswith("scl_decode_kernel")
     # list of one path
     assert kernel(OP_SCL, 1024, 512, F32, 1, OUT_INFO, 0).startswith("scl_decode_kernel")
-    # lists above N = 2048 stay LDS-staged, and so do lists of fewer than 8 paths at N = 2048
-    assert kernel(OP_SCL, 4096, 2048, F32, 16, OUT_INFO, 0).startswith("scl_decode_kernel")
+    # lists of fewer than 8 paths above N = 1024 stay LDS-staged, and so do fp32 calls that want the list
+    assert kernel(OP_SCL, 4096, 2048, F32, 4, OUT_INFO, 0).startswith("scl_decode_kernel")
     assert kernel(OP_SCL, 2048, 1024, F32, 2, OUT_INFO, 0).startswith("scl_decode_kernel")
+    assert kernel(OP_SCL, 2048, 1024, F32, 8, OUT_INFO | OUT_PM, 0).startswith("scl_decode_kernel")
     # the Monte-Carlo kernel exists from N = 128 on
     assert kernel(OP_MC_SC, 64, 32, F32, 0, 0, DQ_FAST | DQ_SPECIALISED).startswith("gen_frames_kernel")
 

@@ -334,16 +334,17 @@ def test_scl_fp64_wide_kernel_equals_lds_kernel(monkeypatch, cons, N, K, L):
     assert np.array_equal(apm, bpm), np.flatnonzero(np.any(apm != bpm, axis=1))[:20]
 
 
-@pytest.mark.parametrize("L,dtype", [(8, np.float32), (16, np.float32), (8, np.float64), (16, np.float64)])
-def test_scl_wide_kernel_at_2048_equals_lds_kernel(monkeypatch, L, dtype):
-    """N = 2048, beyond the eight-lanes-per-path kernel: lists of 8 and 16 on the two-lanes-per-path kernel against the
-    LDS-staged kernel (same operations in the same order): identical bits in fp32, identical bits, survivors and metrics in
-    fp64, frames with exactly tied metrics and with overflowing metrics included."""
-    N, K = 2048, 1024
+@pytest.mark.parametrize("N,L,dtype", [(2048, 8, np.float32), (2048, 16, np.float32), (2048, 8, np.float64), (2048, 16, np.float64),
+                                       (4096, 8, np.float32), (4096, 8, np.float64)])
+def test_scl_wide_kernel_beyond_1024_equals_lds_kernel(monkeypatch, N, L, dtype):
+    """N = 2048 and 4096, beyond the eight-lanes-per-path kernel: lists of 8 and 16 on the two-lanes-per-path kernel against
+    the LDS-staged kernel (same operations in the same order): identical bits in fp32, identical bits, survivors and metrics
+    in fp64, frames with exactly tied metrics and with overflowing metrics included."""
+    K = N // 2
     mask = pcf.degaBuild(N, K, 2.0)
     code = _native.Code(_native.default_ctx(), mask)
     rs = np.random.RandomState(N + L)
-    B = 401 if dtype is np.float32 else 151
+    B = (401 if dtype is np.float32 else 151) * 2048 // N
     x = oracle.polar_encode(rs.randint(0, 2, size=(B, K)), mask).reshape(B, N)
     n0 = 1.0 / (K / N * 10 ** (1.0 / 10))
     llr = code.channel_llr(x, n0, 23, 0, dtype)
@@ -352,7 +353,7 @@ def test_scl_wide_kernel_at_2048_equals_lds_kernel(monkeypatch, L, dtype):
     lists = dtype is np.float64
     monkeypatch.delenv("POLAR_SCL_KERNEL", raising=False)
     a, apm, auh = code.scl_decode(llr, L, want_list=lists)
-    assert code.last_launch()["kernel"].startswith("scl_wide_kernel<11"), code.last_launch()
+    assert code.last_launch()["kernel"].startswith("scl_wide_kernel<%d" % (11 if N == 2048 else 12)), code.last_launch()
     monkeypatch.setenv("POLAR_SCL_KERNEL", "lds")
     b, bpm, buh = code.scl_decode(llr, L, want_list=lists)
     assert code.last_launch()["kernel"].startswith("scl_decode_kernel")
@@ -362,22 +363,24 @@ def test_scl_wide_kernel_at_2048_equals_lds_kernel(monkeypatch, L, dtype):
         assert np.array_equal(apm, bpm), np.flatnonzero(np.any(apm != bpm, axis=1))[:20]
 
 
-def test_scl_wide_kernel_at_2048_with_32_paths_vs_oracle():
-    """N = 2048 with 32 paths, which the LDS-staged kernel has no room for: fp64 against the CPU oracle (the reference's
+@pytest.mark.parametrize("N,L", [(2048, 32), (4096, 16), (4096, 32)])
+def test_scl_wide_kernel_beyond_1024_vs_oracle(N, L):
+    """List sizes the LDS-staged kernel has no room for at N = 2048 and 4096: fp64 against the CPU oracle (the reference's
     arithmetic): decoded bits, the whole sorted list and its metrics, frame by frame; fp32 decodes the same information bits
     on these frames."""
-    N, K, L = 2048, 1024, 32
+    K = N // 2
     mask = pcf.degaBuild(N, K, 2.0)
     code = _native.Code(_native.default_ctx(), mask)
     rs = np.random.RandomState(7)
-    B = 10
+    B = 6
+    nl = 11 if N == 2048 else 12
     x = oracle.polar_encode(rs.randint(0, 2, size=(B, K)), mask).reshape(B, N)
     n0 = 1.0 / (K / N * 10 ** (1.5 / 10))
     llr = code.channel_llr(x, n0, 29, 0, np.float64)
     info, pm, uh = code.scl_decode(llr, L, want_list=True)
-    assert code.last_launch()["kernel"].startswith("scl_wide_kernel<11,double>/L32"), code.last_launch()
+    assert code.last_launch()["kernel"].startswith("scl_wide_kernel<%d,double>/L%d" % (nl, L)), code.last_launch()
     info32, _, _ = code.scl_decode(llr.astype(np.float32), L)
-    assert code.last_launch()["kernel"].startswith("scl_wide_kernel<11>/L32"), code.last_launch()
+    assert code.last_launch()["kernel"].startswith("scl_wide_kernel<%d>/L%d" % (nl, L)), code.last_launch()
     for f in range(B):
         ouh, opm, _ = oracle.scl_decode(llr[f], mask, L)
         assert np.array_equal(uh[f][:len(ouh)], ouh), f
