@@ -183,10 +183,10 @@ def test_gpu_ca_register_kernel_equals_lds_kernel(monkeypatch, N, K, poly):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,K,poly,L", [(256, 128, 0x107, 32), (1024, 536, 0x1800063, 16), (64, 32, 0x1621, 32), (512, 300, 0x107, 16),
-                                          (512, 280, 0x1800063, 32)])
+                                          (512, 280, 0x1800063, 32), (2048, 1048, 0x1800063, 8), (2048, 1048, 0x1800063, 16)])
 def test_gpu_ca_wide_kernel_equals_lds_kernel(monkeypatch, N, K, poly, L):
-    """fp32, L = 16 / 32: the two-lanes-per-path register kernel and the LDS-staged kernel make the same CRC-aided
-    choice, and it is the choice the host makes from the LDS kernel's list."""
+    """fp32, L = 16 / 32 (and 8 at N = 2048): the two-lanes-per-path register kernel and the LDS-staged kernel make the same
+    CRC-aided choice, and it is the choice the host makes from the LDS kernel's list."""
     import _native
 
     mask = pcf.degaBuild(N, K, 2.0)
@@ -194,7 +194,7 @@ def test_gpu_ca_wide_kernel_equals_lds_kernel(monkeypatch, N, K, poly, L):
     n0 = n0_ebn0(0.5, (K - w) / N)
     code = _native.Code(_native.default_ctx(), mask)
     code.set_crc(poly)
-    B = 2000
+    B = 2000 if N <= 1024 else 500
     rs = np.random.RandomState(8)
     word = pcf.crcEncode(rs.randint(0, 2, size=(B, K - w)), poly)
     x = oracle.polar_encode(word, mask)
