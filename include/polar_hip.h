@@ -194,7 +194,7 @@ int polar_sc_decode_flip(polar_code *code, const void *llr, int dtype, const int
  * returns it whether or not its CRC holds); runs [B]: SC runs the reference would have made (1 = no flipping);
  * crc_ok [B]: 1 if the returned word passes the CRC; last_seq [B x 3]: flips of the last run, -1 padded.
  * runs, crc_ok, last_seq may be NULL.  Frames whose first SC run passes the CRC never enter the search.  With two or three
- * flips (N <= 1024) the frames that fail every single flip are searched in (frame, first flip) pieces by all wavefronts of the
+ * flips the frames that fail every single flip are searched in (frame, first flip) pieces by all wavefronts of the
  * GPU, so one frame that needs 10^5 runs does not hold the call: same runs, flips, flags and bits as the sequential search. */
 int polar_pbf_decode(polar_code *code, const void *llr, int dtype, int max_level, uint8_t *info_hat, int32_t *runs,
                      uint8_t *crc_ok, int32_t *last_seq, int64_t B, int space);
