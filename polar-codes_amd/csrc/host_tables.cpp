@@ -159,13 +159,13 @@ const DispatchRow TABLE[] = {
     {DQ_OP_SC, KF_SC_LDS, "sc_decode_kernel<float", F32, 0, 16, 0, 0, ALL_SC, 0, 0, 0, "LDS-staged, any code, every output"},
     {DQ_OP_SC, KF_SC_LDS, "sc_decode_kernel<double", F64, 0, 15, 0, 0, ALL_SC, 0, 0, 0, "LDS-staged, fp64"},
     // ---- SCL (polar_scl_decode*, genie and CRC variants, the list passes of polar_mc_run)
-    {DQ_OP_SCL, KF_SCL_REG, "scl_reg_kernel<", F32, 6, 10, LM(2, 4, 8), 3, DQ_OUT_INFO, 0, 0, DQ_FORCE_LDS, "register-resident, eight lanes per path"},
+    {DQ_OP_SCL, KF_SCL_REG, "scl_reg_kernel<", F32, 6, 10, LM(2, 4, 8), 3, ALL_SCL, 0, 0, DQ_FORCE_LDS, "register-resident, eight lanes per path"},
     {DQ_OP_SCL, KF_SCL_REG, "scl_reg_kernel<", F64, 6, 10, LM(2, 4, 8), 3, ALL_SCL, 0, 0, DQ_FORCE_LDS,
      "the same in fp64 with the sorted list and its metrics"},
-    {DQ_OP_SCL, KF_SCL_WIDE, "scl_wide_kernel<", F32, 6, 10, LM(16, 32), 5, DQ_OUT_INFO, 0, 0, DQ_FORCE_LDS, "register-resident, two lanes per path"},
+    {DQ_OP_SCL, KF_SCL_WIDE, "scl_wide_kernel<", F32, 6, 10, LM(16, 32), 5, ALL_SCL, 0, 0, DQ_FORCE_LDS, "register-resident, two lanes per path"},
     {DQ_OP_SCL, KF_SCL_WIDE, "scl_wide_kernel<", F64, 6, 10, LM(16, 32), 5, ALL_SCL, 0, 0, DQ_FORCE_LDS,
      "the same in fp64 with the sorted list and its metrics"},
-    {DQ_OP_SCL, KF_SCL_WIDE, "scl_wide_kernel<", F32, 11, 12, LM(8, 16, 32), 5, DQ_OUT_INFO, 0, 0, DQ_FORCE_LDS,
+    {DQ_OP_SCL, KF_SCL_WIDE, "scl_wide_kernel<", F32, 11, 12, LM(8, 16, 32), 5, ALL_SCL, 0, 0, DQ_FORCE_LDS,
      "N = 2048, 4096: the two-lanes-per-path kernel also serves L = 8 (a quarter of its lanes at work, still several times the LDS-staged rate)"},
     {DQ_OP_SCL, KF_SCL_WIDE, "scl_wide_kernel<", F64, 11, 12, LM(8, 16, 32), 5, ALL_SCL, 0, 0, DQ_FORCE_LDS, "the same in fp64 with the sorted list and its metrics"},
     {DQ_OP_SCL, KF_SCL_LDS, "scl_decode_kernel<", F32 | F64, 0, 12, LM(1, 2, 4, 8, 16, 32), 0, ALL_SCL, 0, 0, 0, "LDS-staged, every output"},

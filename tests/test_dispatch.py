@@ -47,7 +47,7 @@ CONFIGS = [
     ("C3 fp32", OP_SCL, 1024, 512, F32, 8, OUT_INFO, 0, "scl_reg_kernel"),
     ("C3 fp32 CRC", OP_SCL, 1024, 536, F32, 8, OUT_INFO, DQ_CRC, "scl_reg_kernel"),
     ("C3 fp64 whole list", OP_SCL, 1024, 512, F64, 8, OUT_INFO | OUT_UHAT | OUT_PM, 0, "scl_reg_kernel"),
-    ("C3 fp32 whole list", OP_SCL, 1024, 512, F32, 8, OUT_INFO | OUT_UHAT | OUT_PM, 0, "scl_decode_kernel"),
+    ("C3 fp32 whole list", OP_SCL, 1024, 512, F32, 8, OUT_INFO | OUT_UHAT | OUT_PM, 0, "scl_reg_kernel"),
     # C4 N=512 rate-profiled, L=32
     ("C4 fp32", OP_SCL, 512, 256, F32, 32, OUT_INFO, 0, "scl_wide_kernel"),
     ("C4 fp64 whole list", OP_SCL, 512, 256, F64, 32, OUT_INFO | OUT_UHAT | OUT_PM, 0, "scl_wide_kernel"),
@@ -101,10 +101,10 @@ def test_edges_of_the_register_kernels():
     assert kernel(OP_SCL, 64, 4, F64, 32, OUT_INFO, 0).startswith("scl_decode_kernel")
     # list of one path
     assert kernel(OP_SCL, 1024, 512, F32, 1, OUT_INFO, 0).startswith("scl_decode_kernel")
-    # lists of fewer than 8 paths above N = 1024 stay LDS-staged, and so do fp32 calls that want the list
+    # lists of fewer than 8 paths above N = 1024 stay LDS-staged
     assert kernel(OP_SCL, 4096, 2048, F32, 4, OUT_INFO, 0).startswith("scl_decode_kernel")
     assert kernel(OP_SCL, 2048, 1024, F32, 2, OUT_INFO, 0).startswith("scl_decode_kernel")
-    assert kernel(OP_SCL, 2048, 1024, F32, 8, OUT_INFO | OUT_PM, 0).startswith("scl_decode_kernel")
+    assert kernel(OP_SCL, 2048, 1024, F32, 8, OUT_INFO | OUT_PM, 0).startswith("scl_wide_kernel")
     # the Monte-Carlo kernel exists from N = 128 on
     assert kernel(OP_MC_SC, 64, 32, F32, 0, 0, DQ_FAST | DQ_SPECIALISED).startswith("gen_frames_kernel")
 

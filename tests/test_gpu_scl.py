@@ -389,3 +389,28 @@ def test_scl_wide_kernel_beyond_1024_vs_oracle(N, L):
         np.testing.assert_allclose(pm[f][:len(opm)], opm, rtol=1e-13)
         assert np.array_equal(info[f], ouh[0][np.asarray(mask) == 1]), f
     assert np.array_equal(info32, info)
+
+
+@pytest.mark.parametrize("N,K,L", [(64, 32, 8), (256, 128, 4), (512, 256, 8), (1024, 512, 8), (1024, 512, 2), (128, 64, 32), (512, 256, 32),
+                                   (1024, 512, 16), (2048, 1024, 8), (2048, 1024, 16)])
+def test_scl_fp32_lists_of_the_register_kernels_equal_lds_kernel(monkeypatch, N, K, L):
+    """fp32 with the whole sorted list and its metrics as outputs: both register kernels against the LDS-staged kernel --
+    bits, every survivor and every fp32 metric identical, frames with exactly tied and with overflowing metrics included."""
+    mask = pcf.degaBuild(N, K, 2.0)
+    code = _native.Code(_native.default_ctx(), mask)
+    rs = np.random.RandomState(N + L)
+    B = 400
+    x = oracle.polar_encode(rs.randint(0, 2, size=(B, K)), mask).reshape(B, N)
+    llr = code.channel_llr(x, 1.0 / (K / N * 10 ** 0.1), 31, 0, np.float32)
+    llr[:40] = np.round(llr[:40])
+    llr[40:44] *= 200.0
+    monkeypatch.delenv("POLAR_SCL_KERNEL", raising=False)
+    a, apm, auh = code.scl_decode(llr, L, want_list=True)
+    want = "scl_reg_kernel" if (L <= 8 and N <= 1024) else "scl_wide_kernel"
+    assert code.last_launch()["kernel"].startswith(want), code.last_launch()
+    monkeypatch.setenv("POLAR_SCL_KERNEL", "lds")
+    b, bpm, buh = code.scl_decode(llr, L, want_list=True)
+    assert code.last_launch()["kernel"].startswith("scl_decode_kernel")
+    assert np.array_equal(a, b), np.flatnonzero(np.any(a != b, axis=1))[:20]
+    assert np.array_equal(auh, buh), np.flatnonzero(np.any(auh != buh, axis=(1, 2)))[:20]
+    assert np.array_equal(apm, bpm), np.flatnonzero(np.any(apm != bpm, axis=1))[:20]
