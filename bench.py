@@ -401,6 +401,19 @@ def main():
                                                "frames": nb, "lds_bytes_per_block": li["lds_bytes_per_block"],
                                                "roofline": leg_roofline(li["kernel"], li["last_ms"], nb, 512, 256, paths=32)}
             del l512, h512
+            # list decoding beyond the eight-lanes-per-path kernel: (2048,1024), L = 8 and 32, on the two-lanes-per-path kernel
+            c2k = _native.Code(ctx, pcf.degaBuild(2048, 1024, 2.0))
+            nb = 1 << 15
+            l2k = torch.empty((nb, 2048), dtype=torch.float32, device=dev)
+            c2k.gen_frames_dev(None, l2k.data_ptr(), np.float32, ch.noisePower, seed, 0, nb)
+            h2k = torch.empty((nb, c2k.Kw), dtype=torch.int32, device=dev)
+            for L2 in (8, 32):
+                for _ in range(2):
+                    c2k.scl_decode_dev(l2k.data_ptr(), np.float32, L2, h2k.data_ptr(), nb)
+                li = c2k.last_launch()
+                extras["scl%d_2048_1024" % L2] = {"frames_per_s": nb / (li["last_ms"] * 1e-3), "kernel": li["kernel"], "kernel_ms": li["last_ms"],
+                                                  "frames": nb, "roofline": leg_roofline(li["kernel"], li["last_ms"], nb, 2048, 1024, paths=L2)}
+            del l2k, h2k
             m16k = pcf.degaBuild(16384, 8192, 2.0)
             c16k = _native.Code(ctx, m16k)
             nb = 1 << 15
