@@ -165,9 +165,9 @@ const DispatchRow TABLE[] = {
     {DQ_OP_SCL, KF_SCL_WIDE, "scl_wide_kernel<", F32, 6, 10, LM(16, 32), 5, ALL_SCL, 0, 0, DQ_FORCE_LDS, "register-resident, two lanes per path"},
     {DQ_OP_SCL, KF_SCL_WIDE, "scl_wide_kernel<", F64, 6, 10, LM(16, 32), 5, ALL_SCL, 0, 0, DQ_FORCE_LDS,
      "the same in fp64 with the sorted list and its metrics"},
-    {DQ_OP_SCL, KF_SCL_WIDE, "scl_wide_kernel<", F32, 11, 12, LM(8, 16, 32), 5, ALL_SCL, 0, 0, DQ_FORCE_LDS,
-     "N = 2048, 4096: the two-lanes-per-path kernel also serves L = 8 (a quarter of its lanes at work, still several times the LDS-staged rate)"},
-    {DQ_OP_SCL, KF_SCL_WIDE, "scl_wide_kernel<", F64, 11, 12, LM(8, 16, 32), 5, ALL_SCL, 0, 0, DQ_FORCE_LDS, "the same in fp64 with the sorted list and its metrics"},
+    {DQ_OP_SCL, KF_SCL_WIDE, "scl_wide_kernel<", F32, 11, 12, LM(2, 4, 8, 16, 32), 5, ALL_SCL, 0, 0, DQ_FORCE_LDS,
+     "N = 2048, 4096: the two-lanes-per-path kernel also serves L = 2, 4, 8 (part of its lanes at work, still several times the LDS-staged rate)"},
+    {DQ_OP_SCL, KF_SCL_WIDE, "scl_wide_kernel<", F64, 11, 12, LM(2, 4, 8, 16, 32), 5, ALL_SCL, 0, 0, DQ_FORCE_LDS, "the same in fp64 with the sorted list and its metrics"},
     {DQ_OP_SCL, KF_SCL_LDS, "scl_decode_kernel<", F32 | F64, 0, 12, LM(1, 2, 4, 8, 16, 32), 0, ALL_SCL, 0, 0, 0, "LDS-staged, every output"},
     // ---- progressive bit flipping (polar_pbf_decode*, polar_sc_decode_flip); L = largest number of simultaneous flips
     {DQ_OP_PBF, KF_PBF_REG, "pbf_reg_kernel<", F32 | F64, 5, 10, LM(1), 1, DQ_OUT_INFO, 0, DQ_CRC, DQ_FORCE_LDS | DQ_FLIP_LIST,

@@ -1,5 +1,5 @@
 // Register-resident list decoder for long lists: up to L = 32 paths (L = 16 leaves half of the positions empty; at N = 2048
-// and 4096 also L = 8), N = 64 .. 4096, fp32 or fp64, information bits of the best path (or of the first path in metric order that passes the
+// and 4096 also L = 2, 4, 8), N = 64 .. 4096, fp32 or fp64, information bits of the best path (or of the first path in metric order that passes the
 // CRC / equals the transmitted word) and, when asked for, the whole list in metric order with its metrics: one wavefront
 // per frame, two lanes per path.
 //
@@ -804,10 +804,18 @@ template <int NLOG>
 int launch_wide_l(polar_code *c, const void *llr, int dtype, uint32_t *info_hat, double *pm, uint32_t *u_hat_all, int64_t B, int L, bool crc,
                   const uint32_t *truth)
 {
-    if constexpr (NLOG >= 11) {  // beyond the eight-lanes-per-path kernel: lists of 8 run here with a quarter of the lanes
+    if constexpr (NLOG >= 11) {  // beyond the eight-lanes-per-path kernel: the short lists run here with part of the lanes
         if (L == 8) {
             if (dtype == POLAR_F32) return launch_wide_t<NLOG, 8, float>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
             return launch_wide_t<NLOG, 8, double>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
+        }
+        if (L == 4) {
+            if (dtype == POLAR_F32) return launch_wide_t<NLOG, 4, float>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
+            return launch_wide_t<NLOG, 4, double>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
+        }
+        if (L == 2) {
+            if (dtype == POLAR_F32) return launch_wide_t<NLOG, 2, float>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
+            return launch_wide_t<NLOG, 2, double>(c, llr, info_hat, pm, u_hat_all, B, crc, truth);
         }
     }
     if (dtype == POLAR_F32) {

@@ -59,9 +59,10 @@ CONFIGS = [
     # N = 2048, 4096: lists of 8 and more on the two-lanes-per-path kernel, shorter lists LDS-staged
     ("SCL-8 at 2048", OP_SCL, 2048, 1024, F32, 8, OUT_INFO, 0, "scl_wide_kernel"),
     ("SCL-32 at 2048, fp64 lists", OP_SCL, 2048, 1024, F64, 32, OUT_INFO | OUT_UHAT | OUT_PM, 0, "scl_wide_kernel"),
-    ("SCL-4 at 2048", OP_SCL, 2048, 1024, F32, 4, OUT_INFO, 0, "scl_decode_kernel"),
+    ("SCL-4 at 2048", OP_SCL, 2048, 1024, F32, 4, OUT_INFO, 0, "scl_wide_kernel"),
     ("SCL-8 at 4096", OP_SCL, 4096, 2048, F32, 8, OUT_INFO, 0, "scl_wide_kernel"),
-    ("SCL-4 at 4096", OP_SCL, 4096, 2048, F64, 4, OUT_INFO, 0, "scl_decode_kernel"),
+    ("SCL-4 at 4096", OP_SCL, 4096, 2048, F64, 4, OUT_INFO, 0, "scl_wide_kernel"),
+    ("SCL-1 at 4096", OP_SCL, 4096, 2048, F64, 1, OUT_INFO, 0, "scl_decode_kernel"),
     # flip search on the configuration cn/simulator.py sets (512 message bits + CRC-24)
     ("PBF one flip", OP_PBF, 1024, 536, F32, 1, OUT_INFO, DQ_CRC, "pbf_reg_kernel"),
     ("PBF two flips in pieces", OP_PBF, 1024, 536, F64, 2, OUT_INFO, DQ_CRC | DQ_SPLIT, "pbf_reg_kernel"),
@@ -101,9 +102,9 @@ def test_edges_of_the_register_kernels():
     assert kernel(OP_SCL, 64, 4, F64, 32, OUT_INFO, 0).startswith("scl_decode_kernel")
     # list of one path
     assert kernel(OP_SCL, 1024, 512, F32, 1, OUT_INFO, 0).startswith("scl_decode_kernel")
-    # lists of fewer than 8 paths above N = 1024 stay LDS-staged
-    assert kernel(OP_SCL, 4096, 2048, F32, 4, OUT_INFO, 0).startswith("scl_decode_kernel")
-    assert kernel(OP_SCL, 2048, 1024, F32, 2, OUT_INFO, 0).startswith("scl_decode_kernel")
+    # above N = 1024 every list of two paths and more is on the two-lanes-per-path kernel, with or without the list as output
+    assert kernel(OP_SCL, 4096, 2048, F32, 4, OUT_INFO, 0).startswith("scl_wide_kernel")
+    assert kernel(OP_SCL, 2048, 1024, F32, 2, OUT_INFO, 0).startswith("scl_wide_kernel")
     assert kernel(OP_SCL, 2048, 1024, F32, 8, OUT_INFO | OUT_PM, 0).startswith("scl_wide_kernel")
     # the Monte-Carlo kernel exists from N = 128 on
     assert kernel(OP_MC_SC, 64, 32, F32, 0, 0, DQ_FAST | DQ_SPECIALISED).startswith("gen_frames_kernel")

@@ -335,9 +335,10 @@ def test_scl_fp64_wide_kernel_equals_lds_kernel(monkeypatch, cons, N, K, L):
 
 
 @pytest.mark.parametrize("N,L,dtype", [(2048, 8, np.float32), (2048, 16, np.float32), (2048, 8, np.float64), (2048, 16, np.float64),
-                                       (4096, 8, np.float32), (4096, 8, np.float64)])
+                                       (4096, 8, np.float32), (4096, 8, np.float64), (2048, 4, np.float32), (2048, 2, np.float64),
+                                       (4096, 4, np.float64), (4096, 2, np.float32)])
 def test_scl_wide_kernel_beyond_1024_equals_lds_kernel(monkeypatch, N, L, dtype):
-    """N = 2048 and 4096, beyond the eight-lanes-per-path kernel: lists of 8 and 16 on the two-lanes-per-path kernel against
+    """N = 2048 and 4096, beyond the eight-lanes-per-path kernel: lists of 2 to 16 on the two-lanes-per-path kernel against
     the LDS-staged kernel (same operations in the same order): identical bits in fp32, identical bits, survivors and metrics
     in fp64, frames with exactly tied metrics and with overflowing metrics included."""
     K = N // 2
